@@ -1,0 +1,132 @@
+"""Pins the CPU oracle (oracle/snerf_oracle.py) against golden vectors produced by the REFERENCE's
+own modules (tools/gen_golden.py). CPU only; the oracle is the checker for every GPU parity test."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import snerf_oracle as O
+from tests.helpers import load_fixture, fixture_params, fixture_batch, max_abs, rel_err
+
+TRAIN_CASES = ["sem_siren_small", "sem_relu_small", "sem_variants_small", "sem_tj_small", "sem_cartreg_small",
+               "satnerf_small", "satnerf_relu_small", "sem_siren_full", "satnerf_full_c1"]
+# fp32 oracle vs fp32 reference on the same CPU: same ATen ops, so tight bounds
+OUT_TOL = 2e-6
+GRAD_REL = 2e-5
+
+
+def _run(name):
+    z, meta, cfg = load_fixture(name)
+    p = O.to_torch(fixture_params(z, meta, cfg), requires_grad=True)
+    emb = torch.from_numpy(O.init_embedding_numpy(cfg, meta["seed"])).requires_grad_(True)
+    emb_s = None
+    if cfg.model == "semantic" and cfg.use_separate_tj_for_semantic:
+        emb_s = torch.from_numpy(O.init_embedding_numpy(cfg, meta["seed"] + 1)).requires_grad_(True)
+    b = fixture_batch(z)
+    res = O.render_rays(p, emb, cfg, b["rays"], b["extras"], b["u"], emb_s)
+    depth_res = None
+    if meta["with_depth"]:
+        bd = fixture_batch(z, "in_depth_")
+        depth_res = O.render_rays(p, emb, cfg, bd["rays"], bd["extras"], bd["u"], emb_s)
+    ld = O.training_losses(res, b, cfg, meta["epoch"], depth_res)
+    return z, meta, cfg, p, emb, emb_s, res, depth_res, ld
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_outputs_match_reference(name):
+    z, meta, cfg, p, emb, emb_s, res, depth_res, ld = _run(name)
+    n = 0
+    for k in z.files:
+        if not k.startswith("out_") or k.startswith("out_depth_"):
+            continue
+        key = k[4:]
+        if key == "semantic_label_coarse":
+            assert np.array_equal(res[key].numpy(), z[k]), key
+        else:
+            assert max_abs(res[key].detach(), z[k]) <= OUT_TOL, (key, max_abs(res[key].detach(), z[k]))
+        n += 1
+    assert n >= 4
+    if depth_res is not None:
+        assert max_abs(depth_res["depth_coarse"].detach(), z["out_depth_depth_coarse"]) <= OUT_TOL
+
+
+@pytest.mark.parametrize("name", TRAIN_CASES)
+def test_losses_and_grads_match_reference(name):
+    z, meta, cfg, p, emb, emb_s, res, depth_res, ld = _run(name)
+    ref_terms = {k[5:]: float(z[k]) for k in z.files if k.startswith("loss_") and k != "loss_total"}
+    assert set(ref_terms) == set(ld), (sorted(ref_terms), sorted(ld))
+    for k, v in ref_terms.items():
+        assert abs(float(ld[k].detach()) - v) <= 2e-6 * max(1.0, abs(v)), (k, float(ld[k].detach()), v)
+    O.total_loss(ld).backward()
+    grads = {k: v.grad for k, v in p.items()}
+    grads["model_t.weight"] = emb.grad
+    if emb_s is not None:
+        grads["model_t_s.weight"] = emb_s.grad
+    checked = 0
+    for k in z.files:
+        if k.startswith("grad_"):
+            g = grads[k[5:]]
+            g = torch.zeros_like(p[k[5:]]) if g is None else g
+            assert rel_err(g, z[k]) <= GRAD_REL or max_abs(g, z[k]) <= 1e-9, (k, rel_err(g, z[k]))
+            checked += 1
+        elif k.startswith("gradnorm_"):
+            g = grads[k[9:]]
+            nrm = float(g.double().norm())
+            assert abs(nrm - float(z[k])) <= 1e-4 * max(float(z[k]), 1e-12), (k, nrm, float(z[k]))
+            s = g.detach().reshape(-1)[:: max(1, g.numel() // 64)][:64]
+            assert rel_err(s, z["gradsample_" + k[9:]]) <= 1e-3 or max_abs(s, z["gradsample_" + k[9:]]) <= 1e-8, k
+            checked += 1
+    assert checked >= 20
+
+
+def test_nan_semantics_preserved():
+    """MSE over an empty car set and CE with every target ignored are NaN in the reference
+    (semantic/components/loss.py:147-151; SURVEY hard parts) -- the oracle keeps that."""
+    cfg = O.OracleCfg(fc_units=32, n_samples=8, use_car_reg_loss=True)
+    res = {"weights_coarse": torch.rand(4, 8), "beta_coarse": torch.rand(4, 8, 1),
+           "semantic_logits_coarse": torch.rand(4, 5)}
+    labels = torch.zeros(4, 1, dtype=torch.long)
+    assert torch.isnan(O.car_reg_loss(res, labels, None, cfg)["coarse_car_reg_loss"])
+    labels = torch.full((4, 1), 4, dtype=torch.long)
+    assert torch.isnan(O.semantic_loss(res, labels, None, cfg)["coarse_semantic"])
+
+
+@pytest.mark.parametrize("name", ["inference_sem_small", "inference_satnerf_small"])
+def test_inference_seam(name):
+    z, meta, cfg = load_fixture(name)
+    p = O.to_torch(fixture_params(z, meta, cfg))
+    r = O.inference(p, cfg, torch.from_numpy(z["in_xyz"]), torch.from_numpy(z["in_z"]),
+                    torch.from_numpy(z["in_sun"]), torch.from_numpy(z["in_t"]))
+    for k in z.files:
+        if k.startswith("out_"):
+            if k == "out_semantic_label":
+                assert np.array_equal(r["semantic_label"].numpy(), z[k])
+            else:
+                assert max_abs(r[k[4:]], z[k]) <= OUT_TOL, k
+
+
+def test_adam_trajectory():
+    """a18: Adam(lr 5e-4, wd 0) on the total loss reproduces the reference model's 3-step trajectory."""
+    z, meta, cfg = load_fixture("sem_siren_small")
+    p = O.to_torch(fixture_params(z, meta, cfg), requires_grad=True)
+    emb = torch.from_numpy(O.init_embedding_numpy(cfg, meta["seed"])).requires_grad_(True)
+    b = fixture_batch(z)
+    opt = torch.optim.Adam(list(p.values()) + [emb], lr=5e-4, weight_decay=0)
+    traj = []
+    for _ in range(len(z["adam_traj"])):
+        opt.zero_grad()
+        res = O.render_rays(p, emb, cfg, b["rays"], b["extras"], b["u"])
+        loss = O.total_loss(O.training_losses(res, b, cfg, meta["epoch"]))
+        traj.append(float(loss))
+        loss.backward()
+        opt.step()
+    assert np.allclose(traj, z["adam_traj"], rtol=0, atol=5e-6), (traj, z["adam_traj"])
+
+
+def test_fp64_oracle_close_to_fp32():
+    """The fp64 oracle bounds the fp32 rounding noise of the path (used to set GPU tolerances)."""
+    z, meta, cfg = load_fixture("sem_siren_small")
+    p64 = O.to_torch(fixture_params(z, meta, cfg), dtype=torch.float64)
+    emb = torch.from_numpy(O.init_embedding_numpy(cfg, meta["seed"])).double()
+    b = O.batch_to_torch({k[3:]: z[k] for k in z.files if k.startswith("in_")}, dtype=torch.float64)
+    res = O.render_rays(p64, emb, cfg, b["rays"], b["extras"], b["u"])
+    assert max_abs(res["rgb_coarse"], z["out_rgb_coarse"]) < 1e-4

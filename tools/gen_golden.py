@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the REFERENCE's own hot-path modules.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+
+It imports (read-only) from /root/reference:
+  semantic.models.rs_semantic.{RSSemanticNeRF, inference}, baseline.models.satnerf.{SatNeRF, inference},
+  semantic.components.rendering.RSSemanticRendering, baseline.components.rendering.SatNeRFRendering,
+  baseline.components.loss.*, semantic.components.loss.*
+and writes data-only fixtures (inputs, expected outputs, loss values, gradients) to tests/golden/*.npz.
+
+Weights are NOT drawn from torch's RNG: every parameter is overwritten from the NumPy stream of
+oracle.snerf_oracle.init_params_numpy(cfg, seed) so that tests can regenerate them from (cfg, seed).
+The jitter of sample_rays (framework/components/rendering.py:108) is made reproducible by replacing
+torch.rand_like with a function that returns the stored uniform tensor while render_rays runs.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("SNERF_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+from oracle import snerf_oracle as O  # noqa: E402  (parameter stream + synthetic batches only)
+
+from semantic.models.rs_semantic import RSSemanticNeRF, inference as sem_inference  # noqa: E402
+from baseline.models.satnerf import SatNeRF, inference as sat_inference  # noqa: E402
+from semantic.components.rendering import RSSemanticRendering  # noqa: E402
+from baseline.components.rendering import SatNeRFRendering  # noqa: E402
+from baseline.components.loss import SatNerfLoss, SNerfLoss, DepthLoss  # noqa: E402
+from semantic.components.loss import SemanticLoss, SemanticUncertaintyLoss, SemanticCarRegLoss  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def ref_cfgs(cfg: O.OracleCfg):
+    pipe = types.SimpleNamespace(
+        fc_layers=cfg.fc_layers, fc_units=cfg.fc_units, fc_use_full_features=cfg.fc_use_full_features,
+        fc_skips=list(cfg.fc_skips), activation_function=cfg.activation_function,
+        t_embedding_tau=cfg.t_embedding_tau, mapping_pos_n_freq=cfg.mapping_pos_n_freq, mapping_dir_n_freq=4,
+        use_tj_instead_of_beta=cfg.use_tj_instead_of_beta, use_tj_for_s=cfg.use_tj_for_s,
+        semantic_activation_function=cfg.semantic_activation_function,
+        use_separate_beta_for_s=cfg.use_separate_beta_for_s,
+        use_separate_tj_for_semantic=cfg.use_separate_tj_for_semantic,
+        render_chunk_size=cfg.render_chunk_size, n_samples=cfg.n_samples, sc_lambda=cfg.sc_lambda)
+    return types.SimpleNamespace(pipeline=pipe)
+
+
+def build_reference(cfg: O.OracleCfg, seed: int):
+    cfgs = ref_cfgs(cfg)
+    if cfg.model == "semantic":
+        model = RSSemanticNeRF(cfgs, types.SimpleNamespace(semantic_n_classes=cfg.n_classes))
+        renderer = RSSemanticRendering(cfgs, inference=sem_inference)
+    else:
+        model = SatNeRF(cfgs, layers=cfg.fc_layers, feat=cfg.fc_units, skips=list(cfg.fc_skips),
+                        t_embedding_dims=cfg.t_embedding_tau, siren=cfg.siren)
+        renderer = SatNeRFRendering(cfgs)
+    params = O.init_params_numpy(cfg, seed)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(params.keys()), (list(sd.keys()), list(params.keys()))
+    for k in sd:
+        assert tuple(sd[k].shape) == params[k].shape, (k, sd[k].shape, params[k].shape)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    emb = torch.nn.Embedding(cfg.t_embedding_vocab, cfg.t_embedding_tau)
+    with torch.no_grad():
+        emb.weight.copy_(torch.from_numpy(O.init_embedding_numpy(cfg, seed)))
+    models = {"coarse": model, "t": emb}
+    if cfg.model == "semantic" and cfg.use_separate_tj_for_semantic:
+        emb_s = torch.nn.Embedding(cfg.t_embedding_vocab, cfg.t_embedding_tau)
+        with torch.no_grad():
+            emb_s.weight.copy_(torch.from_numpy(O.init_embedding_numpy(cfg, seed + 1)))
+        models["t_s"] = emb_s
+    return cfgs, models, renderer, params
+
+
+def render_with_u(renderer, models, rays, extras, u):
+    """Run the reference's BaseRenderer.render_rays with its rand_like draw replaced by ``u``."""
+    orig = torch.rand_like
+    calls = []
+
+    def fake(x, *a, **k):
+        calls.append(tuple(x.shape))
+        assert tuple(x.shape) == tuple(u.shape)
+        return u.clone()
+
+    torch.rand_like = fake
+    try:
+        res = renderer.render_rays(models, rays, extras)
+    finally:
+        torch.rand_like = orig
+    assert len(calls) == 1, calls
+    return res
+
+
+def losses_for_epoch(cfg, res, batch, epoch, depth_res=None):
+    """The gate combinations of semantic/components/training_step.py:22-92 applied with the
+    reference's own loss modules."""
+    ld = {}
+    if epoch < cfg.first_beta_epoch:
+        _, d = SNerfLoss(lambda_sc=cfg.sc_lambda)(res, batch["rgbs"])
+    else:
+        _, d = SatNerfLoss(lambda_sc=cfg.sc_lambda)(res, batch["rgbs"])
+    ld.update(d)
+    if depth_res is not None:
+        _, d = DepthLoss(lambda_ds=cfg.ds_lambda)(depth_res, batch["depths"], batch["depth_weights"])
+        ld.update(d)
+    if cfg.model == "semantic":
+        if epoch < cfg.first_beta_epoch or not cfg.use_beta_for_s:
+            _, d = SemanticLoss(cfg.lambda_s, cfg.car_index, ignore_car_index=cfg.ignore_car_index)(
+                res, batch["semantic"], batch["mask"])
+        else:
+            _, d = SemanticUncertaintyLoss(cfg.lambda_s, cfg.car_index, detach_beta_for_s=cfg.detach_beta_for_s,
+                                           ignore_car_index=cfg.ignore_car_index)(res, batch["semantic"], batch["mask"])
+        ld.update(d)
+        if cfg.use_car_reg_loss and epoch >= cfg.car_reg_loss_start:
+            _, d = SemanticCarRegLoss(cfg.lambda_c, cfg.car_index)(res, batch["semantic"], batch["mask"])
+            ld.update(d)
+    return ld
+
+
+def make_case(name, cfg: O.OracleCfg, n_rays, seed, epoch, with_depth=False, store_params=True,
+              per_sample=True, grad_mode="full", adam_steps=0, mask_frac=None, car_prob=0.2):
+    torch.manual_seed(0)
+    cfgs, models, renderer, params = build_reference(cfg, seed)
+    b = O.synthetic_batch(n_rays, cfg.n_samples, seed=seed + 100, n_classes=max(cfg.n_classes, 2), car_prob=car_prob)
+    if mask_frac is not None:
+        rng = np.random.default_rng(seed + 5)
+        b["mask"] = rng.uniform(size=n_rays) > mask_frac
+    bt = O.batch_to_torch(b)
+    fix = {f"in_{k}": v for k, v in b.items()}
+
+    res = render_with_u(renderer, models, bt["rays"], bt["extras"], bt["u"])
+    depth_res = None
+    if with_depth:
+        bd = O.synthetic_batch(n_rays, cfg.n_samples, seed=seed + 200)
+        for k in ("rays", "extras", "u"):
+            fix[f"in_depth_{k}"] = bd[k]
+        bdt = O.batch_to_torch(bd)
+        depth_res = render_with_u(renderer, models, bdt["rays"], bdt["extras"], bdt["u"])
+        fix["out_depth_depth_coarse"] = depth_res["depth_coarse"].detach().numpy()
+    ld = losses_for_epoch(cfg, res, bt, epoch, depth_res)
+    loss = sum(ld.values())
+    for m in models.values():
+        m.zero_grad()
+    loss.backward()
+
+    per_ray_keys = {"rgb_coarse", "depth_coarse", "semantic_logits_coarse", "semantic_label_coarse"}
+    for k, v in res.items():
+        if per_sample or k in per_ray_keys or k in ("weights_coarse", "sigmas_coarse", "weights_sc_coarse",
+                                                    "sun_sc_coarse", "transparency_sc_coarse", "beta_coarse"):
+            fix[f"out_{k}"] = v.detach().numpy()
+    for k, v in ld.items():
+        fix[f"loss_{k}"] = np.float64(v.item())
+    fix["loss_total"] = np.float64(loss.item())
+
+    grads = {k: p.grad.detach().numpy().copy() for k, p in models["coarse"].named_parameters()}
+    grads["model_t.weight"] = models["t"].weight.grad.detach().numpy().copy()
+    if "t_s" in models and models["t_s"].weight.grad is not None:
+        grads["model_t_s.weight"] = models["t_s"].weight.grad.detach().numpy().copy()
+    for k, g in grads.items():
+        if grad_mode == "full":
+            fix[f"grad_{k}"] = g
+        else:  # norms + a strided sample (full-width case: weights regenerate from the seed)
+            fix[f"gradnorm_{k}"] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+            fix[f"gradsample_{k}"] = g.reshape(-1)[:: max(1, g.size // 64)][:64].copy()
+    if store_params:
+        for k, v in params.items():
+            fix[f"param_{k}"] = v
+
+    if adam_steps:
+        # a18: Adam(lr=5e-4, wd=0) trajectory on the reference model (base_ray_pipeline.py:246-254)
+        plist = [p for m in models.values() for p in m.parameters()]
+        opt = torch.optim.Adam(plist, lr=5e-4, weight_decay=0)
+        traj = [loss.item()]
+        opt.step()
+        for _ in range(adam_steps):
+            opt.zero_grad()
+            r = render_with_u(renderer, models, bt["rays"], bt["extras"], bt["u"])
+            l = sum(losses_for_epoch(cfg, r, bt, epoch).values())
+            traj.append(l.item())
+            l.backward()
+            opt.step()
+        fix["adam_traj"] = np.array(traj, dtype=np.float64)
+
+    meta = dict(name=name, seed=seed, epoch=epoch, n_rays=n_rays, with_depth=with_depth,
+                cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(cfg).items()},
+                torch=torch.__version__, reference="wagnva/semantic-nerf-for-satellite-data@2025-03-21")
+    fix["meta_json"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **fix)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, loss={loss.item():.6f}, terms={ {k: round(v.item(), 6) for k, v in ld.items()} }")
+
+
+def inference_case(name, cfg: O.OracleCfg, n_rays, seed):
+    """Seam 3: reference inference(model, cfgs, xyz, z_vals, ...) on explicit xyz / z_vals."""
+    cfgs, models, renderer, params = build_reference(cfg, seed)
+    rng = np.random.default_rng(seed + 300)
+    S = cfg.n_samples
+    z = np.sort(rng.uniform(0.0, 1.5, (n_rays, S)).astype(np.float32), axis=1)
+    xyz = rng.uniform(-1.2, 1.2, (n_rays, S, 3)).astype(np.float32)
+    sun = rng.standard_normal((n_rays, 3)).astype(np.float32)
+    sun /= np.linalg.norm(sun, axis=1, keepdims=True)
+    t = rng.standard_normal((n_rays, cfg.t_embedding_tau)).astype(np.float32)
+    with torch.no_grad():
+        if cfg.model == "semantic":
+            r = sem_inference(models["coarse"], cfgs, torch.from_numpy(xyz), torch.from_numpy(z), rays_d=None,
+                              sun_d=torch.from_numpy(sun), rays_t=torch.from_numpy(t), rays_t_s=None)
+        else:
+            r = sat_inference(models["coarse"], cfgs, torch.from_numpy(xyz), torch.from_numpy(z), rays_d=None,
+                              sun_d=torch.from_numpy(sun), rays_t=torch.from_numpy(t))
+    fix = dict(in_xyz=xyz, in_z=z, in_sun=sun, in_t=t)
+    for k, v in r.items():
+        fix[f"out_{k}"] = v.numpy()
+    for k, v in params.items():
+        fix[f"param_{k}"] = v
+    meta = dict(name=name, seed=seed, n_rays=n_rays, cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(cfg).items()})
+    fix["meta_json"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **fix)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    small = dict(fc_units=32, n_samples=16, render_chunk_size=200)  # chunk < P: exercises the chunk loop
+    # A: default semantic config at reduced width, beta loss active
+    make_case("sem_siren_small", O.OracleCfg(**small), 48, seed=1, epoch=2, adam_steps=3)
+    # B: relu trunk, no sigmoid on the semantic head, epoch 0 (plain MSE), masked rays
+    make_case("sem_relu_small", O.OracleCfg(activation_function="relu", semantic_activation_function="none",
+                                            ignore_car_index=False, **small), 48, seed=2, epoch=0, mask_frac=0.3)
+    # C: beta_s head + t_j into the semantic head + beta-weighted CE + L_t
+    make_case("sem_variants_small", O.OracleCfg(use_tj_for_s=True, use_separate_beta_for_s=True, use_beta_for_s=True,
+                                                use_car_reg_loss=True, **small), 48, seed=3, epoch=3)
+    # D: t_j instead of beta into rgb head, separate t_s embedding for semantics, sc off, full-width heads
+    make_case("sem_tj_small", O.OracleCfg(use_tj_instead_of_beta=True, use_tj_for_s=True,
+                                          use_separate_tj_for_semantic=True, sc_lambda=0.0,
+                                          fc_use_full_features=True, **small), 40, seed=4, epoch=0)
+    # E: L_t alone on the default head set (config 3's loss set)
+    make_case("sem_cartreg_small", O.OracleCfg(use_car_reg_loss=True, **small), 64, seed=5, epoch=3)
+    # F: baseline SatNeRF (config 1 shape family) with the depth-ray pass
+    make_case("satnerf_small", O.OracleCfg(model="satnerf", fc_units=32, n_samples=8, render_chunk_size=100),
+              40, seed=6, epoch=2, with_depth=True)
+    make_case("satnerf_relu_small", O.OracleCfg(model="satnerf", activation_function="relu", fc_units=32, n_samples=8),
+              40, seed=7, epoch=0)
+    # G: full width (W=512, S=64), few rays; weights regenerate from the seed
+    make_case("sem_siren_full", O.OracleCfg(), 16, seed=8, epoch=2, store_params=False, per_sample=False,
+              grad_mode="sample")
+    make_case("satnerf_full_c1", O.OracleCfg(model="satnerf", n_samples=32), 16, seed=9, epoch=2,
+              store_params=False, per_sample=False, grad_mode="sample")
+    # H: seam-3 inference on explicit xyz/z_vals
+    inference_case("inference_sem_small", O.OracleCfg(**small), 24, seed=10)
+    inference_case("inference_satnerf_small", O.OracleCfg(model="satnerf", fc_units=32, n_samples=8), 24, seed=11)
+
+
+if __name__ == "__main__":
+    main()
