@@ -1,0 +1,173 @@
+/*
+ * snerf_hip.h -- C-ABI of libsnerf_hip.so: the MI355X (gfx950) implementation of the semantic
+ * Sat-NeRF ray-marching hot path (encode -> SIREN/ReLU MLP + heads -> irradiance alpha-composite
+ * -> losses, forward and backward).
+ *
+ * The reference (wagnva/semantic-nerf-for-satellite-data) is pure Python/PyTorch and has no FFI of
+ * its own; each entry point below names the reference interface it replaces (paths relative to the
+ * reference repository).  INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch types; every pointer is a DEVICE pointer on the
+ *     current HIP device unless stated otherwise; row-major fp32 unless stated otherwise;
+ *   - return 0 on success, non-zero error code otherwise; snerf_last_error() gives the message;
+ *     no exceptions cross the ABI;
+ *   - no allocation and no synchronisation inside the hot calls: the caller provides the workspace
+ *     (size from snerf_workspace_bytes) and a stream; calls are asynchronous on that stream
+ *     (hipGraph-capturable);
+ *   - one caller thread per device/stream (the reference drives everything from one Python thread,
+ *     framework/pipelines.py:306-320); re-entrant across devices (one process per GPU).
+ */
+#ifndef SNERF_HIP_H
+#define SNERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNERF_ABI_VERSION 1
+#define SNERF_MAX_LAYERS 16
+
+/* error codes */
+#define SNERF_OK 0
+#define SNERF_ERR_BAD_DESC 1
+#define SNERF_ERR_WORKSPACE 2
+#define SNERF_ERR_NULL 3
+#define SNERF_ERR_HIP 4
+
+/* SnerfDesc.flags */
+#define SNERF_FLAG_TRAIN 1u   /* keep every activation needed by snerf_backward in the workspace */
+#define SNERF_FLAG_SC_PASS 2u /* solar-correction variant: sample points on o + sun_d*z, evaluate only the
+                                 trunk + sigma + sun-visibility branch and return weights/transparency/sun
+                                 (semantic/components/rendering.py:59-78) */
+
+/* Model + batch description.  Field names follow the reference config
+ * (configs/pipelines/rs_semantic.toml:13-67, semantic/pipelines/rs_semantic.py:125-141). */
+typedef struct SnerfDesc {
+  int32_t n_rays;      /* N */
+  int32_t n_samples;   /* S (n_samples) */
+  int32_t fc_units;    /* W */
+  int32_t fc_layers;   /* L <= SNERF_MAX_LAYERS */
+  int32_t feat_last;   /* H = W/2, or W with fc_use_full_features */
+  uint32_t skip_mask;  /* bit i set <=> i in fc_skips */
+  int32_t n_freq;      /* mapping_pos_n_freq; 0 = identity encoding (baseline SatNeRF, satnerf.py:140-141) */
+  int32_t siren;       /* activation_function == "siren" */
+  int32_t t_dim;       /* t_embedding_tau */
+  int32_t n_classes;   /* semantic classes C; 0 = baseline SatNeRF without semantic head */
+  int32_t sem_sigmoid; /* semantic_activation_function == "sigmoid" */
+  int32_t use_tj_instead_of_beta;
+  int32_t use_tj_for_s;
+  int32_t use_separate_beta_for_s;
+  int32_t use_separate_tj_for_semantic;
+  uint32_t flags;
+} SnerfDesc;
+
+/* Raw device pointers to the parameter tensors, in the reference's state_dict layout
+ * (fc_net.{2i}.{weight,bias}, sigma_from_xyz.0.*, feats_from_xyz.*, rgb_from_xyzdir.{0,2}.*,
+ * semantic_prediction.{0,2}.*, sun_v_net.{0,2,4,6}.*, sky_color.{0,2}.*, beta_from_xyz.{0,2}.*,
+ * semantic_beta_from_xyz.{0,2}.*).  torch Linear layout: weight (out,in) row-major contiguous, bias (out).
+ * The library never owns them.  Used both for parameters (read) and for their gradients (written). */
+typedef struct SnerfParams {
+  float* fc_w[SNERF_MAX_LAYERS];
+  float* fc_b[SNERF_MAX_LAYERS];
+  float* sigma_w; float* sigma_b;
+  float* feats_w; float* feats_b;
+  float* rgb_w0; float* rgb_b0; float* rgb_w2; float* rgb_b2;
+  float* sem_w0; float* sem_b0; float* sem_w2; float* sem_b2;       /* NULL when n_classes == 0 */
+  float* sun_w[4]; float* sun_b[4];
+  float* sky_w0; float* sky_b0; float* sky_w2; float* sky_b2;
+  float* beta_w0; float* beta_b0; float* beta_w2; float* beta_b2;
+  float* sbeta_w0; float* sbeta_b0; float* sbeta_w2; float* sbeta_b2; /* NULL unless use_separate_beta_for_s */
+} SnerfParams;
+
+/* Ray batch.  Either (rays [+ z_vals | z_steps [+ u]]) -- the renderer seam,
+ * framework/components/rendering.py:84-157 -- or explicit (xyz, z_vals) -- the inference() seam,
+ * semantic/models/rs_semantic.py:8-19. */
+typedef struct SnerfInputs {
+  const float* rays;    /* (N,8): origin 0:3, dir 3:6, near 6, far 7 (framework/components/rays.py:7-38) */
+  const float* xyz;     /* (N,S,3) explicit sample positions, or NULL */
+  const float* z_vals;  /* (N,S) explicit depths, or NULL => stratified sampling from rays */
+  const float* z_steps; /* (S) = linspace(0,1,S) from the host; needed when z_vals == NULL */
+  const float* u;       /* (N,S) uniform [0,1) jitter, or NULL => no perturbation */
+  const float* sun_d;   /* (N,3) with row stride sun_stride floats (4 when pointing into extras (N,4)) */
+  int32_t sun_stride;
+  int32_t _pad;
+  const float* t;       /* (N,tau) transient embedding rows (models["t"](ts)) */
+  const float* t_s;     /* (N,tau) or NULL */
+} SnerfInputs;
+
+/* Result tensors = the dict returned by inference() (rs_semantic.py:111-128); any pointer may be NULL.
+ * With SNERF_FLAG_SC_PASS only weights / transparency / sun are produced. */
+typedef struct SnerfOutputs {
+  float* rgb;             /* (N,3)  */
+  float* depth;           /* (N)    */
+  float* weights;         /* (N,S)  */
+  float* transparency;    /* (N,S)  */
+  float* albedo;          /* (N,S,3)*/
+  float* sun;             /* (N,S,1)*/
+  float* sky;             /* (N,S,3)*/
+  float* beta;            /* (N,S,1)*/
+  float* sigmas;          /* (N,S)  */
+  float* beta_semantic;   /* (N,S,1) if use_separate_beta_for_s */
+  float* semantic_logits; /* (N,C)  */
+  int64_t* semantic_label;/* (N)    */
+  float* z_vals;          /* (N,S) depths actually used (sampled or copied) */
+} SnerfOutputs;
+
+/* Gradients of the scalar loss w.r.t. the result tensors (same shapes; NULL = zero). */
+typedef struct SnerfOutGrads {
+  const float* rgb; const float* depth; const float* weights; const float* transparency;
+  const float* albedo; const float* sun; const float* sky; const float* beta; const float* sigmas;
+  const float* beta_semantic; const float* semantic_logits;
+} SnerfOutGrads;
+
+/* ---- library info ------------------------------------------------------------------------------ */
+int snerf_version(void);
+const char* snerf_last_error(void);
+
+/* ---- sizes (host-side, no GPU work) -------------------------------------------------------------- */
+/* number of floats of the packed parameter / packed gradient buffer */
+size_t snerf_packed_floats(const SnerfDesc* desc);
+/* workspace bytes for one pass (activations + scratch) under desc->flags; the same buffer must be
+ * handed to snerf_backward for that pass */
+size_t snerf_workspace_bytes(const SnerfDesc* desc);
+
+/* ---- parameter packing ------------------------------------------------------------------------- */
+/* Gather the state_dict tensors into the padded, MFMA-friendly packed layout (DESIGN.md "Data layout").
+ * Replaces nothing in the reference (torch.nn.Linear owns its layout there); run once per optimiser step. */
+int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* packed, void* stream);
+/* Scatter packed gradients back into tensors shaped like the parameters (overwrite, or add if accumulate). */
+int snerf_unpack_grads(const SnerfDesc* desc, const float* packed_grads, const SnerfParams* grads,
+                       int accumulate, void* stream);
+
+/* ---- hot path ---------------------------------------------------------------------------------- */
+/* One rendering pass: sample -> encode -> MLP -> composite.
+ * Replaces BaseRenderer.render_rays/sample_rays (framework/components/rendering.py:84-157),
+ * RSSemanticRendering._model_rendering (semantic/components/rendering.py:18-80; one call per pass),
+ * inference + RSSemanticNeRF.forward (semantic/models/rs_semantic.py:8-128,260-340;
+ * baseline/models/satnerf.py:8-98,203-255) and convert_sigmas (framework/util/rendering.py:4-34). */
+int snerf_forward(const SnerfDesc* desc, const float* packed_params, const SnerfInputs* in,
+                  const SnerfOutputs* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of one pass (what autograd does in the reference for the ops above): consumes the
+ * activations that snerf_forward(SNERF_FLAG_TRAIN) left in `workspace`, ACCUMULATES parameter
+ * gradients into packed_grads (caller zeroes it once per step) and writes d loss / d t (N,tau)
+ * [and d t_s] when those pointers are non-NULL. */
+int snerf_backward(const SnerfDesc* desc, const float* packed_params, const SnerfInputs* in,
+                   const SnerfOutGrads* gout, float* packed_grads, float* d_t, float* d_t_s,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- test hook: the tiled fp32-MFMA GEMM used by every layer --------------------------------------
+ * C[I,J] = sum_k A(i,k) * B(j,k);  a_ic/b_ic = 0: operand stored (rows, K) K-contiguous,
+ * 1: stored (K, rows) row-contiguous.  Exposed so tests can check the MFMA tiling in isolation. */
+int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, int b_ic,
+                    float* C, int ldc, int I, int J, int K, int narrow, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNERF_HIP_H */

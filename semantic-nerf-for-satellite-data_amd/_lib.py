@@ -1,0 +1,100 @@
+"""ctypes binding of libsnerf_hip.so -- mirrors include/snerf_hip.h field for field."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnerf_hip.so")
+MAX_LAYERS = 16
+
+FLAG_TRAIN = 1
+FLAG_SC_PASS = 2
+
+_fp = C.POINTER(C.c_float)
+
+
+class SnerfDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_rays", "n_samples", "fc_units", "fc_layers", "feat_last")] + [
+        ("skip_mask", C.c_uint32)] + [(n, C.c_int32) for n in (
+            "n_freq", "siren", "t_dim", "n_classes", "sem_sigmoid", "use_tj_instead_of_beta", "use_tj_for_s",
+            "use_separate_beta_for_s", "use_separate_tj_for_semantic")] + [("flags", C.c_uint32)]
+
+
+_PARAM_FIELDS = (["sigma_w", "sigma_b", "feats_w", "feats_b", "rgb_w0", "rgb_b0", "rgb_w2", "rgb_b2",
+                  "sem_w0", "sem_b0", "sem_w2", "sem_b2"], ["sky_w0", "sky_b0", "sky_w2", "sky_b2",
+                                                             "beta_w0", "beta_b0", "beta_w2", "beta_b2",
+                                                             "sbeta_w0", "sbeta_b0", "sbeta_w2", "sbeta_b2"])
+
+
+class SnerfParams(C.Structure):
+    _fields_ = ([("fc_w", C.c_void_p * MAX_LAYERS), ("fc_b", C.c_void_p * MAX_LAYERS)]
+                + [(n, C.c_void_p) for n in _PARAM_FIELDS[0]]
+                + [("sun_w", C.c_void_p * 4), ("sun_b", C.c_void_p * 4)]
+                + [(n, C.c_void_p) for n in _PARAM_FIELDS[1]])
+
+
+class SnerfInputs(C.Structure):
+    _fields_ = [("rays", C.c_void_p), ("xyz", C.c_void_p), ("z_vals", C.c_void_p), ("z_steps", C.c_void_p),
+                ("u", C.c_void_p), ("sun_d", C.c_void_p), ("sun_stride", C.c_int32), ("_pad", C.c_int32),
+                ("t", C.c_void_p), ("t_s", C.c_void_p)]
+
+
+OUTPUT_FIELDS = ("rgb", "depth", "weights", "transparency", "albedo", "sun", "sky", "beta", "sigmas",
+                 "beta_semantic", "semantic_logits", "semantic_label", "z_vals")
+GRAD_FIELDS = ("rgb", "depth", "weights", "transparency", "albedo", "sun", "sky", "beta", "sigmas",
+               "beta_semantic", "semantic_logits")
+
+
+class SnerfOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in OUTPUT_FIELDS]
+
+
+class SnerfOutGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in GRAD_FIELDS]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; no fallback of any kind."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libsnerf_hip.so not found at {LIB_PATH}: the HIP extension is the product path and has no "
+            "fallback. Build it with `make -C semantic-nerf-for-satellite-data_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`).")
+    L = C.CDLL(LIB_PATH)
+    L.snerf_version.restype = C.c_int
+    L.snerf_last_error.restype = C.c_char_p
+    L.snerf_packed_floats.restype = C.c_size_t
+    L.snerf_packed_floats.argtypes = [C.POINTER(SnerfDesc)]
+    L.snerf_workspace_bytes.restype = C.c_size_t
+    L.snerf_workspace_bytes.argtypes = [C.POINTER(SnerfDesc)]
+    L.snerf_pack_params.restype = C.c_int
+    L.snerf_pack_params.argtypes = [C.POINTER(SnerfDesc), C.POINTER(SnerfParams), C.c_void_p, C.c_void_p]
+    L.snerf_unpack_grads.restype = C.c_int
+    L.snerf_unpack_grads.argtypes = [C.POINTER(SnerfDesc), C.c_void_p, C.POINTER(SnerfParams), C.c_int, C.c_void_p]
+    L.snerf_forward.restype = C.c_int
+    L.snerf_forward.argtypes = [C.POINTER(SnerfDesc), C.c_void_p, C.POINTER(SnerfInputs), C.POINTER(SnerfOutputs),
+                                C.c_void_p, C.c_size_t, C.c_void_p]
+    L.snerf_backward.restype = C.c_int
+    L.snerf_backward.argtypes = [C.POINTER(SnerfDesc), C.c_void_p, C.POINTER(SnerfInputs), C.POINTER(SnerfOutGrads),
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.snerf_test_gemm.restype = C.c_int
+    L.snerf_test_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    if L.snerf_version() != 1:
+        raise RuntimeError(f"libsnerf_hip.so ABI version {L.snerf_version()} != 1")
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {lib().snerf_last_error().decode()}")
+
+
+EXPORTED_SYMBOLS = ("snerf_version", "snerf_last_error", "snerf_packed_floats", "snerf_workspace_bytes",
+                    "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward", "snerf_test_gemm")

@@ -1,0 +1,530 @@
+// C-ABI of libsnerf_hip.so (include/snerf_hip.h): layout plan, parameter packing and the
+// forward / backward launch sequences of one rendering pass.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "aux_kernels.h"
+#include "composite.h"
+#include "gemm.h"
+#include "plan.h"
+
+namespace snerf {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------------
+int make_plan(const SnerfDesc* d, Plan* pl) {
+  if (!d || !pl) { set_error("null descriptor"); return SNERF_ERR_NULL; }
+  Plan& p = *pl;
+  auto bad = [&](const char* why) { set_error("bad SnerfDesc: %s", why); return SNERF_ERR_BAD_DESC; };
+  if (d->n_rays <= 0 || d->n_samples <= 0) return bad("n_rays and n_samples must be positive");
+  if ((long long)d->n_rays * d->n_samples > (1ll << 30)) return bad("n_rays * n_samples too large for one pass (chunk the rays)");
+  if (d->fc_layers < 1 || d->fc_layers > SNERF_MAX_LAYERS) return bad("fc_layers out of range");
+  if (d->fc_units < 4 || (d->fc_units & 3)) return bad("fc_units must be a positive multiple of 4");
+  if (d->feat_last < 4 || (d->feat_last & 3) || d->feat_last > 64 * MAX_SKY_UNITS) return bad("feat_last must be a multiple of 4, <= 512");
+  if (d->n_freq < 0 || d->n_freq > 16) return bad("n_freq out of range");
+  if (d->t_dim < 1 || d->t_dim > 16) return bad("t_dim out of range");
+  if (d->n_classes < 0 || d->n_classes > MAX_CLASSES) return bad("n_classes out of range");
+  if (d->skip_mask & 1u) return bad("layer 0 cannot be a skip layer");
+  p.N = d->n_rays; p.S = d->n_samples; p.P = p.N * p.S; p.Pp = round_up(p.P, 128);
+  p.W = d->fc_units; p.H = d->feat_last; p.L = d->fc_layers; p.F = d->n_freq;
+  p.E = p.F > 0 ? 6 * p.F : 3; p.Ep = round_up(p.E, 4);
+  p.tau = d->t_dim; p.C = d->n_classes;
+  p.siren = d->siren != 0; p.sem_sigmoid = d->sem_sigmoid != 0;
+  p.train = (d->flags & SNERF_FLAG_TRAIN) != 0; p.sc = (d->flags & SNERF_FLAG_SC_PASS) != 0;
+  p.skip_mask = d->skip_mask;
+  const bool sem = p.C > 0;
+  const bool sbeta = sem && d->use_separate_beta_for_s;
+  const bool sep_ts = sem && d->use_separate_tj_for_semantic;
+  p.rgb_t = sem && d->use_tj_instead_of_beta;
+  p.sem_t = sem && d->use_tj_for_s && !sep_ts;
+  p.sem_ts = sem && d->use_tj_for_s && sep_ts;
+  p.sbeta_ts = sbeta && sep_ts;
+  p.x_sun = 0; p.x_t = 3; p.x_ts = sep_ts ? 3 + p.tau : -1;
+  p.Xp = round_up(3 + p.tau + (sep_ts ? p.tau : 0), 4);
+  p.FA = p.W + p.Xp;
+  int nb = 0;
+  p.blk_rgb = nb++;
+  p.blk_sem = sem ? nb++ : -1;
+  p.blk_beta = nb++;
+  p.blk_sbeta = sbeta ? nb++ : -1;
+  p.blk_sun = nb++;
+  p.nblk = nb;
+  p.N1 = nb * p.H;
+  p.KF = (nb - 1) * p.H;
+
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += round_up_sz(n, 64); return o; };
+  for (int i = 0; i < p.L; ++i) {
+    p.k_tr[i] = (i == 0) ? p.Ep : (((p.skip_mask >> i) & 1u) ? p.Ep + p.W : p.W);
+    p.w_tr[i] = take((size_t)p.W * p.k_tr[i]);
+    p.b_tr[i] = take(p.W);
+  }
+  p.w_fs = take((size_t)(p.W + NARROW) * p.W); p.b_fs = take(p.W + NARROW);
+  p.w_h1 = take((size_t)p.N1 * p.FA); p.b_h1 = take(p.N1);
+  p.w_s2 = take((size_t)p.H * p.H); p.b_s2 = take(p.H);
+  p.w_s3 = take((size_t)p.H * p.H); p.b_s3 = take(p.H);
+  p.w_s4 = take((size_t)NARROW * p.H); p.b_s4 = take(NARROW);
+  p.w_fin = take((size_t)NARROW * p.KF); p.b_fin = take(NARROW);
+  p.sky_floats = 9 * p.H + 4;
+  p.sky = take(p.sky_floats);
+  p.packed_floats = off;
+
+  // ---- workspace
+  size_t wo = 0;
+  auto wtake = [&](size_t floats) { size_t o = wo; wo += round_up_sz(floats * sizeof(float), 256); return o; };
+  const size_t Pp = p.Pp;
+  p.h1w = p.sc ? p.H : p.N1;
+  p.o_z = wtake((size_t)p.P + 4);
+  p.o_T = wtake(p.P);
+  p.o_rgbraw = wtake((size_t)p.N * 3);
+  p.o_pe = wtake(Pp * p.Ep);
+  const bool keep_c = p.train && p.siren;
+  if (p.train) {
+    for (int i = 0; i < p.L; ++i) p.o_h[i] = wtake(Pp * p.W);
+    for (int i = 0; i < p.L; ++i) p.o_c[i] = keep_c ? wtake(Pp * p.W) : 0;
+  } else {
+    const size_t a = wtake(Pp * p.W), b = wtake(Pp * p.W);
+    for (int i = 0; i < p.L; ++i) { p.o_h[i] = (i & 1) ? b : a; p.o_c[i] = 0; }
+  }
+  p.o_fa = wtake(Pp * p.FA);
+  p.o_h1 = wtake(Pp * p.h1w);
+  p.o_c1 = keep_c ? wtake(Pp * p.h1w) : 0;
+  p.o_s2 = wtake(Pp * p.H); p.o_s3 = wtake(Pp * p.H);
+  p.o_cs2 = keep_c ? wtake(Pp * p.H) : 0; p.o_cs3 = keep_c ? wtake(Pp * p.H) : 0;
+  p.o_sigo = wtake(Pp * NARROW); p.o_fino = wtake(Pp * NARROW); p.o_suno = wtake(Pp * NARROW);
+  p.maxw = p.W > p.FA ? p.W : p.FA;
+  if (p.h1w > p.maxw) p.maxw = p.h1w;
+  p.nrb = (p.P + 31) / 32;
+  p.comp_blocks = composite_bwd_blocks(p.N);
+  if (p.train) {
+    p.o_dza = wtake(Pp * p.maxw); p.o_dzb = wtake(Pp * p.maxw);
+    p.o_dsa = wtake(Pp * p.H); p.o_dsb = wtake(Pp * p.H);
+    p.o_dsig = wtake(Pp * NARROW); p.o_dfin = wtake(Pp * NARROW); p.o_dsun = wtake(Pp * NARROW);
+    p.o_colsum = wtake((size_t)p.nrb * p.maxw);
+    p.o_colsum2 = wtake((size_t)64 * (p.maxw > p.sky_floats ? p.maxw : p.sky_floats));
+    // dW split-K: ~4096 contraction rows per split, at most 64 splits
+    int ns = (p.P + 4095) / 4096;
+    if (ns > 64) ns = 64;
+    if (ns < 1) ns = 1;
+    p.k_split = round_up((p.P + ns - 1) / ns, 32);
+    p.n_split = (p.P + p.k_split - 1) / p.k_split;
+    size_t biggest = (size_t)p.N1 * p.FA;
+    for (int i = 0; i < p.L; ++i) if ((size_t)p.W * p.k_tr[i] > biggest) biggest = (size_t)p.W * p.k_tr[i];
+    if ((size_t)(p.W + NARROW) * p.W > biggest) biggest = (size_t)(p.W + NARROW) * p.W;
+    if ((size_t)NARROW * p.KF > biggest) biggest = (size_t)NARROW * p.KF;
+    p.slab_floats = round_up_sz(biggest, 64);
+    p.o_slab = wtake(p.slab_floats * p.n_split);
+    p.o_skyslab = wtake((size_t)p.comp_blocks * 4 * p.sky_floats);
+  }
+  p.ws_bytes = wo;
+  return SNERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pack / unpack tables
+// ---------------------------------------------------------------------------------------------------
+struct TableBuilder {
+  CopyTable tabs[4];
+  int nt = 0;
+  bool missing = false;
+  TableBuilder() { memset(tabs, 0, sizeof(tabs)); nt = 1; }
+  void add(float* user, int user_ld, int rows, int cols, size_t dst_off, int dst_ld) {
+    if (!user) { missing = true; return; }
+    if (tabs[nt - 1].n == COPY_TABLE_MAX) ++nt;
+    CopyEntry& e = tabs[nt - 1].e[tabs[nt - 1].n++];
+    e.user = user; e.user_ld = user_ld; e.rows = rows; e.cols = cols; e.dst_off = dst_off; e.dst_ld = dst_ld;
+  }
+};
+
+static void build_tables(const Plan& p, const SnerfParams* w, TableBuilder& tb) {
+  const int W = p.W, H = p.H, E = p.E;
+  for (int i = 0; i < p.L; ++i) {
+    const bool skip = (p.skip_mask >> i) & 1u;
+    if (i == 0) {
+      tb.add(w->fc_w[0], E, W, E, p.w_tr[0], p.k_tr[0]);
+    } else if (skip) {  // [gamma | h] columns: gamma -> [0,E), h -> [Ep, Ep+W)
+      tb.add(w->fc_w[i], E + W, W, E, p.w_tr[i], p.k_tr[i]);
+      tb.add(w->fc_w[i] ? w->fc_w[i] + E : nullptr, E + W, W, W, p.w_tr[i] + p.Ep, p.k_tr[i]);
+    } else {
+      tb.add(w->fc_w[i], W, W, W, p.w_tr[i], p.k_tr[i]);
+    }
+    tb.add(w->fc_b[i], W, 1, W, p.b_tr[i], W);
+  }
+  tb.add(w->feats_w, W, W, W, p.w_fs, W);
+  tb.add(w->sigma_w, W, 1, W, p.w_fs + (size_t)W * W, W);
+  tb.add(w->feats_b, W, 1, W, p.b_fs, W);
+  tb.add(w->sigma_b, 1, 1, 1, p.b_fs + W, 1);
+  auto head1 = [&](int blk, float* w0, float* b0, int extra, int xcol) {
+    const int in = W + extra;
+    const size_t row0 = p.w_h1 + (size_t)blk * H * p.FA;
+    tb.add(w0, in, H, W, row0, p.FA);
+    if (extra > 0) tb.add(w0 ? w0 + W : nullptr, in, H, extra, row0 + W + xcol, p.FA);
+    tb.add(b0, H, 1, H, p.b_h1 + (size_t)blk * H, H);
+  };
+  head1(p.blk_rgb, w->rgb_w0, w->rgb_b0, p.rgb_t ? p.tau : 0, p.x_t);
+  if (p.blk_sem >= 0) head1(p.blk_sem, w->sem_w0, w->sem_b0, (p.sem_t || p.sem_ts) ? p.tau : 0, p.sem_ts ? p.x_ts : p.x_t);
+  head1(p.blk_beta, w->beta_w0, w->beta_b0, p.tau, p.x_t);
+  if (p.blk_sbeta >= 0) head1(p.blk_sbeta, w->sbeta_w0, w->sbeta_b0, p.tau, p.sbeta_ts ? p.x_ts : p.x_t);
+  head1(p.blk_sun, w->sun_w[0], w->sun_b[0], 3, p.x_sun);
+  tb.add(w->sun_w[1], H, H, H, p.w_s2, H); tb.add(w->sun_b[1], H, 1, H, p.b_s2, H);
+  tb.add(w->sun_w[2], H, H, H, p.w_s3, H); tb.add(w->sun_b[2], H, 1, H, p.b_s3, H);
+  tb.add(w->sun_w[3], H, 1, H, p.w_s4, H); tb.add(w->sun_b[3], 1, 1, 1, p.b_s4, 1);
+  auto fin = [&](int blk, int col, int rows, float* w2, float* b2) {
+    tb.add(w2, H, rows, H, p.w_fin + (size_t)col * p.KF + (size_t)blk * H, p.KF);
+    tb.add(b2, rows, 1, rows, p.b_fin + col, rows);
+  };
+  fin(p.blk_rgb, Plan::col_rgb, 3, w->rgb_w2, w->rgb_b2);
+  fin(p.blk_beta, Plan::col_beta, 1, w->beta_w2, w->beta_b2);
+  if (p.blk_sbeta >= 0) fin(p.blk_sbeta, Plan::col_sbeta, 1, w->sbeta_w2, w->sbeta_b2);
+  if (p.blk_sem >= 0) fin(p.blk_sem, Plan::col_sem, p.C, w->sem_w2, w->sem_b2);
+  tb.add(w->sky_w0, 3, H, 3, p.sky, 4);
+  tb.add(w->sky_b0, H, 1, H, p.sky + 4 * (size_t)H, H);
+  tb.add(w->sky_w2, H, 3, H, p.sky + 5 * (size_t)H, H);
+  tb.add(w->sky_b2, 3, 1, 3, p.sky + 9 * (size_t)H, 3);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+struct WS {
+  char* base;
+  float* f(size_t off) const { return reinterpret_cast<float*>(base + off); }
+};
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutputs* out, WS ws,
+                        hipStream_t st) {
+  const int P = p.P, W = p.W, H = p.H;
+  float* z = ws.f(p.o_z);
+  // 1. depths
+  if (in->z_vals) {
+    SNERF_HIP_CHECK(hipMemcpyAsync(z, in->z_vals, sizeof(float) * P, hipMemcpyDeviceToDevice, st));
+  } else {
+    RC(launch_sample_z(in->rays, in->z_steps, in->u, z, p.N, p.S, st));
+  }
+  if (out->z_vals) SNERF_HIP_CHECK(hipMemcpyAsync(out->z_vals, z, sizeof(float) * P, hipMemcpyDeviceToDevice, st));
+  // 2. positions + encoding + extras
+  EncodeArgs ea;
+  ea.rays = in->xyz ? nullptr : in->rays; ea.xyz = in->xyz; ea.z = z;
+  ea.sun_d = in->sun_d; ea.sun_stride = in->sun_stride; ea.t = in->t; ea.t_s = in->t_s;
+  ea.dir_is_sun = (p.sc && !in->xyz) ? 1 : 0;
+  ea.N = p.N; ea.S = p.S; ea.F = p.F; ea.Ep = p.Ep; ea.pe = ws.f(p.o_pe);
+  ea.fa = ws.f(p.o_fa); ea.FA = p.FA; ea.W = W; ea.Xp = p.Xp; ea.x_sun = p.x_sun; ea.x_t = p.x_t; ea.x_ts = p.x_ts; ea.tau = p.tau;
+  RC(launch_encode(ea, st));
+  // 3. trunk (rs_semantic.py:325-334)
+  const int act = p.siren ? ACT_SIN : ACT_RELU;
+  for (int i = 0; i < p.L; ++i) {
+    GemmArgs g;
+    const bool skip = (p.skip_mask >> i) & 1u;
+    if (i == 0) { g.A = ws.f(p.o_pe); g.lda = p.Ep; }
+    else if (skip) { g.A = ws.f(p.o_pe); g.lda = p.Ep; g.Ka = p.Ep; g.A2 = ws.f(p.o_h[i - 1]); g.lda2 = W; }
+    else { g.A = ws.f(p.o_h[i - 1]); g.lda = W; }
+    g.B = pk + p.w_tr[i]; g.ldb = p.k_tr[i];
+    g.I = P; g.J = W; g.K = p.k_tr[i];
+    g.C = ws.f(p.o_h[i]); g.ldc = W;
+    g.bias = pk + p.b_tr[i]; g.act = act; g.w0 = (p.siren && i == 0) ? 30.f : 1.f;
+    g.C2 = (p.train && p.siren) ? ws.f(p.o_c[i]) : nullptr;
+    RC(launch_gemm(g, st));
+  }
+  const float* hl = ws.f(p.o_h[p.L - 1]);
+  {  // sigma pre-activation (rs_semantic.py:337) -> NARROW-wide buffer, column 0
+    GemmArgs g;
+    g.A = hl; g.lda = W; g.B = pk + p.w_fs + (size_t)W * W; g.ldb = W; g.I = P; g.J = NARROW; g.K = W;
+    g.C = ws.f(p.o_sigo); g.ldc = NARROW; g.bias = pk + p.b_fs + W; g.narrow_j = true;
+    RC(launch_gemm(g, st));
+  }
+  {  // feats (rs_semantic.py:338), written into the first W columns of the [feats | sun | t | t_s] buffer
+    GemmArgs g;
+    g.A = hl; g.lda = W; g.B = pk + p.w_fs; g.ldb = W; g.I = P; g.J = W; g.K = W;
+    g.C = ws.f(p.o_fa); g.ldc = p.FA; g.bias = pk + p.b_fs;
+    RC(launch_gemm(g, st));
+  }
+  {  // first layer of every head in one GEMM (sc pass: sun-visibility block only)
+    GemmArgs g;
+    g.A = ws.f(p.o_fa); g.lda = p.FA; g.I = P; g.K = p.FA;
+    const size_t r0 = p.sc ? (size_t)p.blk_sun * H : 0;
+    g.B = pk + p.w_h1 + r0 * p.FA; g.ldb = p.FA; g.J = p.h1w;
+    g.C = ws.f(p.o_h1); g.ldc = p.h1w; g.bias = pk + p.b_h1 + r0; g.act = act; g.w0 = 1.f;
+    g.C2 = (p.train && p.siren) ? ws.f(p.o_c1) : nullptr;
+    RC(launch_gemm(g, st));
+  }
+  const int sun_col = p.sc ? 0 : p.blk_sun * H;
+  {  // sun visibility layers 2,3 (rs_semantic.py:217-227)
+    GemmArgs g;
+    g.A = ws.f(p.o_h1) + sun_col; g.lda = p.h1w; g.B = pk + p.w_s2; g.ldb = H; g.I = P; g.J = H; g.K = H;
+    g.C = ws.f(p.o_s2); g.ldc = H; g.bias = pk + p.b_s2; g.act = act;
+    g.C2 = (p.train && p.siren) ? ws.f(p.o_cs2) : nullptr;
+    RC(launch_gemm(g, st));
+    g.A = ws.f(p.o_s2); g.lda = H; g.B = pk + p.w_s3; g.bias = pk + p.b_s3; g.C = ws.f(p.o_s3);
+    g.C2 = (p.train && p.siren) ? ws.f(p.o_cs3) : nullptr;
+    RC(launch_gemm(g, st));
+  }
+  {  // sun visibility output pre-activation
+    GemmArgs g;
+    g.A = ws.f(p.o_s3); g.lda = H; g.B = pk + p.w_s4; g.ldb = H; g.I = P; g.J = NARROW; g.K = H;
+    g.C = ws.f(p.o_suno); g.ldc = NARROW; g.bias = pk + p.b_s4; g.narrow_j = true;
+    RC(launch_gemm(g, st));
+  }
+  if (!p.sc) {  // last layer of rgb / beta / beta_s / semantic heads: block-diagonal [NARROW][KF]
+    GemmArgs g;
+    g.A = ws.f(p.o_h1); g.lda = p.h1w; g.B = pk + p.w_fin; g.ldb = p.KF; g.I = P; g.J = NARROW; g.K = p.KF;
+    g.C = ws.f(p.o_fino); g.ldc = NARROW; g.bias = pk + p.b_fin; g.narrow_j = true;
+    RC(launch_gemm(g, st));
+  }
+  // 4. composite
+  CompArgs c;
+  c.N = p.N; c.S = p.S; c.H = H; c.C = p.C; c.sc = p.sc; c.sem_sigmoid = p.sem_sigmoid; c.has_sbeta = p.blk_sbeta >= 0;
+  c.z = z; c.sigo = ws.f(p.o_sigo); c.fino = ws.f(p.o_fino); c.suno = ws.f(p.o_suno);
+  c.sun_d = in->sun_d; c.sun_stride = in->sun_stride; c.sky = pk + p.sky;
+  c.o_rgb = out->rgb; c.o_depth = out->depth; c.o_weights = out->weights; c.o_transparency = out->transparency;
+  c.o_albedo = out->albedo; c.o_sun = out->sun; c.o_sky = out->sky; c.o_beta = out->beta; c.o_sigmas = out->sigmas;
+  c.o_beta_s = out->beta_semantic; c.o_logits = out->semantic_logits; c.o_label = (long long*)out->semantic_label;
+  if (p.train) { c.save_T = ws.f(p.o_T); c.save_rgbraw = ws.f(p.o_rgbraw); }
+  RC(launch_composite_fwd(c, st));
+  return SNERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------
+// dW = dZ^T X over all points, split-K into slabs, then one deterministic reduction into g (+=).
+static int dw_gemm(const Plan& p, WS ws, const float* dz, int lddz, int I, bool narrow_i, const float* X, int ldx,
+                   int J, size_t slab_off, int ldw, hipStream_t st) {
+  GemmArgs g;
+  g.A = dz; g.lda = lddz; g.a_ic = true; g.B = X; g.ldb = ldx; g.b_ic = true;
+  g.I = I; g.J = J; g.K = p.P;
+  g.C = ws.f(p.o_slab) + slab_off; g.ldc = ldw;
+  g.k_split = p.k_split; g.n_split = p.n_split; g.slab_stride = p.slab_floats; g.narrow_i = narrow_i;
+  return launch_gemm(g, st);
+}
+static int dw_reduce(const Plan& p, WS ws, size_t count, float* gout, hipStream_t st) {
+  return launch_reduce_rows(ws.f(p.o_slab), p.n_split, p.slab_floats, (int)count, gout, 0, p.n_split, 1, st);
+}
+static int bias_from_colsum(const Plan& p, WS ws, int width, float* gout, hipStream_t st) {
+  return reduce_partials(ws.f(p.o_colsum), p.nrb, (size_t)p.maxw, width, ws.f(p.o_colsum2), gout, st);
+}
+static int bias_from_narrow(const Plan& p, WS ws, const float* dnar, float* gout, hipStream_t st) {
+  const int nb = (p.P + 1023) / 1024;
+  RC(launch_colsum32(dnar, p.P, ws.f(p.o_colsum), st));
+  return reduce_partials(ws.f(p.o_colsum), nb, NARROW, NARROW, ws.f(p.o_colsum2), gout, st);
+}
+
+static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutGrads* go, float* gp,
+                         float* d_t, float* d_t_s, WS ws, hipStream_t st) {
+  const int P = p.P, W = p.W, H = p.H;
+  const int aux_mode = p.siren ? AUX_MUL : AUX_RELU_MASK;
+  // activation-derivative source for a buffer: saved w0*cos (siren) or the activation itself (relu mask)
+  auto dact = [&](size_t o_c, size_t o_h) { return p.siren ? ws.f(o_c) : ws.f(o_h); };
+  float* dsig = ws.f(p.o_dsig); float* dfin = ws.f(p.o_dfin); float* dsun = ws.f(p.o_dsun);
+  // 0. composite backward -> gradients of the NARROW-wide pre-activations (+ sky MLP grads)
+  CompBwdArgs b;
+  CompArgs& c = b.f;
+  c.N = p.N; c.S = p.S; c.H = H; c.C = p.C; c.sc = p.sc; c.sem_sigmoid = p.sem_sigmoid; c.has_sbeta = p.blk_sbeta >= 0;
+  c.z = ws.f(p.o_z); c.sigo = ws.f(p.o_sigo); c.fino = ws.f(p.o_fino); c.suno = ws.f(p.o_suno);
+  c.sun_d = in->sun_d; c.sun_stride = in->sun_stride; c.sky = pk + p.sky;
+  b.T = ws.f(p.o_T); b.rgbraw = ws.f(p.o_rgbraw);
+  b.g_rgb = go->rgb; b.g_depth = go->depth; b.g_weights = go->weights; b.g_transparency = go->transparency;
+  b.g_albedo = go->albedo; b.g_sun = go->sun; b.g_sky = go->sky; b.g_beta = go->beta; b.g_sigmas = go->sigmas;
+  b.g_beta_s = go->beta_semantic; b.g_logits = go->semantic_logits;
+  b.d_sigo = dsig; b.d_fino = dfin; b.d_suno = dsun; b.sky_slab = p.sc ? nullptr : ws.f(p.o_skyslab);
+  RC(launch_composite_bwd(b, st));
+  if (!p.sc)
+    RC(reduce_partials(ws.f(p.o_skyslab), p.comp_blocks * 4, (size_t)p.sky_floats, p.sky_floats, ws.f(p.o_colsum2),
+                       gp + p.sky, st));
+
+  float* dz1 = ws.f(p.o_dza);  // d(pre-activation) of the fused first head layer, [P][h1w]
+  const int sun_col = p.sc ? 0 : p.blk_sun * H;
+  if (!p.sc) {
+    // 1. final head layers
+    RC(dw_gemm(p, ws, dfin, NARROW, NARROW, true, ws.f(p.o_h1), p.h1w, p.KF, 0, p.KF, st));
+    RC(dw_reduce(p, ws, (size_t)NARROW * p.KF, gp + p.w_fin, st));
+    RC(bias_from_narrow(p, ws, dfin, gp + p.b_fin, st));
+    GemmArgs g;  // dz1[:, :KF] = (dfin . W_fin) * act'
+    g.A = dfin; g.lda = NARROW; g.B = pk + p.w_fin; g.ldb = p.KF; g.b_ic = true; g.I = P; g.J = p.KF; g.K = NARROW;
+    g.C = dz1; g.ldc = p.h1w; g.aux = dact(p.o_c1, p.o_h1); g.ldaux = p.h1w; g.aux_mode = aux_mode;
+    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
+    RC(launch_gemm(g, st));
+    RC(bias_from_colsum(p, ws, p.KF, gp + p.b_h1, st));
+  }
+  {  // 2. sun visibility chain: output layer, layer 3, layer 2
+    RC(dw_gemm(p, ws, dsun, NARROW, NARROW, true, ws.f(p.o_s3), H, H, 0, H, st));
+    RC(dw_reduce(p, ws, (size_t)NARROW * H, gp + p.w_s4, st));
+    RC(bias_from_narrow(p, ws, dsun, gp + p.b_s4, st));
+    GemmArgs g;
+    g.A = dsun; g.lda = NARROW; g.B = pk + p.w_s4; g.ldb = H; g.b_ic = true; g.I = P; g.J = H; g.K = NARROW;
+    g.C = ws.f(p.o_dsa); g.ldc = H; g.aux = dact(p.o_cs3, p.o_s3); g.ldaux = H; g.aux_mode = aux_mode;
+    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
+    RC(launch_gemm(g, st));  // dz_s3
+    RC(bias_from_colsum(p, ws, H, gp + p.b_s3, st));
+    RC(dw_gemm(p, ws, ws.f(p.o_dsa), H, H, false, ws.f(p.o_s2), H, H, 0, H, st));
+    RC(dw_reduce(p, ws, (size_t)H * H, gp + p.w_s3, st));
+    g.A = ws.f(p.o_dsa); g.lda = H; g.B = pk + p.w_s3; g.K = H;
+    g.C = ws.f(p.o_dsb); g.aux = dact(p.o_cs2, p.o_s2);
+    RC(launch_gemm(g, st));  // dz_s2
+    RC(bias_from_colsum(p, ws, H, gp + p.b_s2, st));
+    RC(dw_gemm(p, ws, ws.f(p.o_dsb), H, H, false, ws.f(p.o_h1) + sun_col, p.h1w, H, 0, H, st));
+    RC(dw_reduce(p, ws, (size_t)H * H, gp + p.w_s2, st));
+    g.A = ws.f(p.o_dsb); g.B = pk + p.w_s2;
+    g.C = dz1 + sun_col; g.ldc = p.h1w; g.aux = dact(p.o_c1, p.o_h1) + sun_col; g.ldaux = p.h1w;
+    RC(launch_gemm(g, st));  // dz1[:, sun block]
+    RC(bias_from_colsum(p, ws, H, gp + p.b_h1 + (size_t)p.blk_sun * H, st));
+  }
+  float* dfa = ws.f(p.o_dzb);  // [P][FA]
+  {  // 3. fused first head layer: dW, then d[feats | extras]
+    const size_t r0 = p.sc ? (size_t)p.blk_sun * H : 0;
+    RC(dw_gemm(p, ws, dz1, p.h1w, p.h1w, false, ws.f(p.o_fa), p.FA, p.FA, 0, p.FA, st));
+    RC(dw_reduce(p, ws, (size_t)p.h1w * p.FA, gp + p.w_h1 + r0 * p.FA, st));
+    GemmArgs g;
+    g.A = dz1; g.lda = p.h1w; g.B = pk + p.w_h1 + r0 * p.FA; g.ldb = p.FA; g.b_ic = true;
+    g.I = P; g.J = p.FA; g.K = p.h1w; g.C = dfa; g.ldc = p.FA;
+    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;  // columns [0,W) = bias grad of feats_from_xyz
+    RC(launch_gemm(g, st));
+    RC(bias_from_colsum(p, ws, W, gp + p.b_fs, st));
+    if (d_t) RC(launch_ray_sum(dfa, p.FA, W + p.x_t, p.N, p.S, p.tau, d_t, st));
+    if (d_t_s && p.x_ts >= 0) RC(launch_ray_sum(dfa, p.FA, W + p.x_ts, p.N, p.S, p.tau, d_t_s, st));
+  }
+  float* dz = ws.f(p.o_dza);  // dz1 is dead from here on
+  {  // 4. feats + sigma: dW for the [W + NARROW][W] matrix, then dz of the last trunk layer
+    const float* hl = ws.f(p.o_h[p.L - 1]);
+    RC(dw_gemm(p, ws, dfa, p.FA, W, false, hl, W, W, 0, W, st));
+    RC(dw_gemm(p, ws, dsig, NARROW, NARROW, true, hl, W, W, (size_t)W * W, W, st));
+    RC(dw_reduce(p, ws, (size_t)(W + NARROW) * W, gp + p.w_fs, st));
+    RC(bias_from_narrow(p, ws, dsig, gp + p.b_fs + W, st));
+    GemmArgs g;
+    g.A = dfa; g.lda = p.FA; g.Ka = W; g.A2 = dsig; g.lda2 = NARROW;
+    g.B = pk + p.w_fs; g.ldb = W; g.b_ic = true; g.I = P; g.J = W; g.K = W + NARROW;
+    g.C = dz; g.ldc = W; g.aux = dact(p.o_c[p.L - 1], p.o_h[p.L - 1]); g.ldaux = W; g.aux_mode = aux_mode;
+    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
+    RC(launch_gemm(g, st));
+    RC(bias_from_colsum(p, ws, W, gp + p.b_tr[p.L - 1], st));
+  }
+  // 5. trunk, last layer to first
+  float* dz_cur = dz;
+  float* dz_nxt = ws.f(p.o_dzb);
+  for (int i = p.L - 1; i >= 0; --i) {
+    const bool skip = (p.skip_mask >> i) & 1u;
+    const int hoff = (i > 0 && skip) ? p.Ep : 0;  // column of the h part inside W_i
+    if (i == 0 || skip) RC(dw_gemm(p, ws, dz_cur, W, W, false, ws.f(p.o_pe), p.Ep, p.Ep, 0, p.k_tr[i], st));
+    if (i > 0) RC(dw_gemm(p, ws, dz_cur, W, W, false, ws.f(p.o_h[i - 1]), W, W, hoff, p.k_tr[i], st));
+    RC(dw_reduce(p, ws, (size_t)W * p.k_tr[i], gp + p.w_tr[i], st));
+    if (i == 0) break;
+    GemmArgs g;
+    g.A = dz_cur; g.lda = W; g.B = pk + p.w_tr[i] + hoff; g.ldb = p.k_tr[i]; g.b_ic = true;
+    g.I = P; g.J = W; g.K = W; g.C = dz_nxt; g.ldc = W;
+    g.aux = dact(p.o_c[i - 1], p.o_h[i - 1]); g.ldaux = W; g.aux_mode = aux_mode;
+    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
+    RC(launch_gemm(g, st));
+    RC(bias_from_colsum(p, ws, W, gp + p.b_tr[i - 1], st));
+    float* t = dz_cur; dz_cur = dz_nxt; dz_nxt = t;
+  }
+  return SNERF_OK;
+}
+
+static int check_inputs(const Plan& p, const SnerfInputs* in) {
+  if (!in) { set_error("null inputs"); return SNERF_ERR_NULL; }
+  if (!in->sun_d || in->sun_stride < 3) { set_error("sun_d (N,3) with stride >= 3 is required"); return SNERF_ERR_NULL; }
+  if (!in->t) { set_error("t (N,tau) is required"); return SNERF_ERR_NULL; }
+  if (p.x_ts >= 0 && !in->t_s) { set_error("t_s is required with use_separate_tj_for_semantic"); return SNERF_ERR_NULL; }
+  if (in->xyz) {
+    if (!in->z_vals) { set_error("explicit xyz needs explicit z_vals"); return SNERF_ERR_NULL; }
+  } else {
+    if (!in->rays) { set_error("rays or xyz is required"); return SNERF_ERR_NULL; }
+    if (!in->z_vals && !in->z_steps) { set_error("z_steps is required when z_vals is not given"); return SNERF_ERR_NULL; }
+  }
+  return SNERF_OK;
+}
+
+}  // namespace snerf
+
+// =====================================================================================================
+using namespace snerf;
+
+extern "C" {
+
+int snerf_version(void) { return SNERF_ABI_VERSION; }
+const char* snerf_last_error(void) { return g_err; }
+
+size_t snerf_packed_floats(const SnerfDesc* desc) {
+  Plan p;
+  if (make_plan(desc, &p)) return 0;
+  return p.packed_floats;
+}
+
+size_t snerf_workspace_bytes(const SnerfDesc* desc) {
+  Plan p;
+  if (make_plan(desc, &p)) return 0;
+  return p.ws_bytes;
+}
+
+int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* packed, void* stream) {
+  Plan p;
+  RC(make_plan(desc, &p));
+  if (!params || !packed) { set_error("null params/packed"); return SNERF_ERR_NULL; }
+  TableBuilder tb;
+  build_tables(p, params, tb);
+  if (tb.missing) { set_error("snerf_pack_params: a parameter tensor required by this SnerfDesc is NULL"); return SNERF_ERR_NULL; }
+  hipStream_t st = (hipStream_t)stream;
+  SNERF_HIP_CHECK(hipMemsetAsync(packed, 0, p.packed_floats * sizeof(float), st));
+  for (int i = 0; i < tb.nt; ++i) RC(launch_copy_table(tb.tabs[i], packed, 0, st));
+  return SNERF_OK;
+}
+
+int snerf_unpack_grads(const SnerfDesc* desc, const float* packed_grads, const SnerfParams* grads, int accumulate,
+                       void* stream) {
+  Plan p;
+  RC(make_plan(desc, &p));
+  if (!grads || !packed_grads) { set_error("null grads"); return SNERF_ERR_NULL; }
+  TableBuilder tb;
+  build_tables(p, grads, tb);
+  if (tb.missing) { set_error("snerf_unpack_grads: a gradient tensor required by this SnerfDesc is NULL"); return SNERF_ERR_NULL; }
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < tb.nt; ++i) RC(launch_copy_table(tb.tabs[i], const_cast<float*>(packed_grads), accumulate ? 2 : 1, st));
+  return SNERF_OK;
+}
+
+int snerf_forward(const SnerfDesc* desc, const float* packed_params, const SnerfInputs* in, const SnerfOutputs* out,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+  Plan p;
+  RC(make_plan(desc, &p));
+  if (!packed_params || !out || !workspace) { set_error("snerf_forward: null argument"); return SNERF_ERR_NULL; }
+  if (workspace_bytes < p.ws_bytes) { set_error("snerf_forward: workspace too small (%zu < %zu)", workspace_bytes, p.ws_bytes); return SNERF_ERR_WORKSPACE; }
+  if (((uintptr_t)workspace & 255) || ((uintptr_t)packed_params & 255)) { set_error("workspace and packed params must be 256-byte aligned"); return SNERF_ERR_WORKSPACE; }
+  RC(check_inputs(p, in));
+  WS ws{(char*)workspace};
+  return forward_impl(p, packed_params, in, out, ws, (hipStream_t)stream);
+}
+
+int snerf_backward(const SnerfDesc* desc, const float* packed_params, const SnerfInputs* in, const SnerfOutGrads* gout,
+                   float* packed_grads, float* d_t, float* d_t_s, void* workspace, size_t workspace_bytes, void* stream) {
+  Plan p;
+  RC(make_plan(desc, &p));
+  if (!p.train) { set_error("snerf_backward needs the SnerfDesc used for the SNERF_FLAG_TRAIN forward"); return SNERF_ERR_BAD_DESC; }
+  if (!packed_params || !gout || !packed_grads || !workspace) { set_error("snerf_backward: null argument"); return SNERF_ERR_NULL; }
+  if (workspace_bytes < p.ws_bytes) { set_error("snerf_backward: workspace too small (%zu < %zu)", workspace_bytes, p.ws_bytes); return SNERF_ERR_WORKSPACE; }
+  if (((uintptr_t)workspace & 255) || ((uintptr_t)packed_params & 255) || ((uintptr_t)packed_grads & 255)) { set_error("workspace and packed buffers must be 256-byte aligned"); return SNERF_ERR_WORKSPACE; }
+  RC(check_inputs(p, in));
+  WS ws{(char*)workspace};
+  return backward_impl(p, packed_params, in, gout, packed_grads, d_t, d_t_s, ws, (hipStream_t)stream);
+}
+
+int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, int b_ic, float* C, int ldc, int I,
+                    int J, int K, int narrow, void* stream) {
+  GemmArgs g;
+  g.A = A; g.lda = lda; g.a_ic = a_ic != 0; g.B = B; g.ldb = ldb; g.b_ic = b_ic != 0;
+  g.C = C; g.ldc = ldc; g.I = I; g.J = J; g.K = K;
+  g.narrow_j = narrow == 1; g.narrow_i = narrow == 2;
+  return launch_gemm(g, (hipStream_t)stream);
+}
+
+}  // extern "C"

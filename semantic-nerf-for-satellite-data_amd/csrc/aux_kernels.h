@@ -1,0 +1,34 @@
+#pragma once
+#include "common.h"
+#include "../../include/snerf_hip.h"
+
+namespace snerf {
+
+struct EncodeArgs {
+  const float* rays = nullptr;   // (N,8) or null when xyz given
+  const float* xyz = nullptr;    // (N,S,3) explicit positions
+  const float* z = nullptr;      // (N,S)
+  const float* sun_d = nullptr; int sun_stride = 3;
+  const float* t = nullptr; const float* t_s = nullptr;
+  int dir_is_sun = 0;            // solar-correction pass: x = o + sun_d * z
+  int N = 0, S = 0, F = 0, Ep = 0;
+  float* pe = nullptr;           // [P][Ep]
+  float* fa = nullptr; int FA = 0, W = 0, Xp = 0, x_sun = 0, x_t = 3, x_ts = -1, tau = 0;
+};
+
+struct CopyEntry {
+  float* user; int user_ld; int rows; int cols; unsigned long long dst_off; int dst_ld;
+};
+constexpr int COPY_TABLE_MAX = 40;
+struct CopyTable { CopyEntry e[COPY_TABLE_MAX]; int n; };
+
+int launch_sample_z(const float* rays, const float* zsteps, const float* u, float* z, int N, int S, hipStream_t st);
+int launch_encode(const EncodeArgs& a, hipStream_t st);
+int launch_copy_table(const CopyTable& tb, float* packed, int mode, hipStream_t st);
+int launch_reduce_rows(const float* in, int n_in, size_t in_stride, int width, float* out, size_t out_stride,
+                       int group, int accumulate, hipStream_t st);
+int reduce_partials(const float* in, int n_in, size_t in_stride, int width, float* tmp, float* out, hipStream_t st);
+int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st);
+int launch_ray_sum(const float* dfa, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st);
+
+}  // namespace snerf

@@ -1,0 +1,203 @@
+// Small HBM-bound kernels around the GEMMs: ray sampling, positional encoding, parameter
+// (un)packing, slab reductions.  All are launched with shapes checked on the host (api.hip).
+#include "aux_kernels.h"
+
+namespace snerf {
+
+// ---- stratified sampling: z = lower + (upper - lower) * u ------------------------------------------
+// framework/components/rendering.py:95-110.  Every product/sum is rounded separately (no FMA
+// contraction) so z is bit-identical to the reference's chain of elementwise ATen ops.
+__device__ __forceinline__ float z_lin(float near, float far, float s) {
+  return __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, s)), __fmul_rn(far, s));
+}
+
+__global__ void sample_z_kernel(const float* __restrict__ rays, const float* __restrict__ zsteps,
+                                const float* __restrict__ u, float* __restrict__ z, int N, int S) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N * S) return;
+  const int n = g / S, j = g - n * S;
+  const float near = rays[n * 8 + 6], far = rays[n * 8 + 7];
+  const float zj = z_lin(near, far, zsteps[j]);
+  float out = zj;
+  if (u != nullptr) {
+    float lower = zj, upper = zj;
+    if (j > 0) lower = __fmul_rn(0.5f, __fadd_rn(z_lin(near, far, zsteps[j - 1]), zj));
+    if (j < S - 1) upper = __fmul_rn(0.5f, __fadd_rn(zj, z_lin(near, far, zsteps[j + 1])));
+    out = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u[g]));
+  }
+  z[g] = out;
+}
+
+int launch_sample_z(const float* rays, const float* zsteps, const float* u, float* z, int N, int S,
+                    hipStream_t st) {
+  const int n = N * S;
+  hipLaunchKernelGGL(sample_z_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rays, zsteps, u, z, N, S);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- sample position + positional encoding + per-sample extras ----------------------------------------
+// x = o + d*z (framework/components/rendering.py:113-115; d = sun_d for the solar-correction pass,
+// semantic/components/rendering.py:61-63); gamma(x) = [sin(2^k x), cos(2^k x)]_k, 3-wide blocks, no raw x
+// (baseline/models/commons.py:58-74); identity for the baseline SatNeRF.  One thread per (point, k):
+// the F threads of a point write one contiguous Ep-float row.  The k == 0 thread also writes the
+// [sun | t | t_s] columns behind the feats columns (never materialised by repeat_interleave as in
+// rs_semantic.py:42-61; written once per sample because the head GEMM reads them as K columns).
+__global__ void encode_kernel(EncodeArgs a) {
+  const int F = a.F > 0 ? a.F : 1;
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long point = g / F;
+  const int k = (int)(g - point * F);
+  if (point >= (long long)a.N * a.S) return;
+  const int n = (int)(point / a.S);
+  float x[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (a.xyz != nullptr) {
+      x[c] = a.xyz[point * 3 + c];
+    } else {
+      const float o = a.rays[n * 8 + c];
+      const float d = a.dir_is_sun ? a.sun_d[(size_t)n * a.sun_stride + c] : a.rays[n * 8 + 3 + c];
+      x[c] = __fadd_rn(o, __fmul_rn(d, a.z[point]));
+    }
+  }
+  float* pe = a.pe + point * a.Ep;
+  if (a.F > 0) {
+    const float f = (float)(1 << k);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float s, co;
+      sincos_acc(f * x[c], &s, &co);
+      pe[k * 6 + c] = s;
+      pe[k * 6 + 3 + c] = co;
+    }
+  } else {
+    pe[0] = x[0]; pe[1] = x[1]; pe[2] = x[2]; pe[3] = 0.f;
+  }
+  if (k == 0 && a.fa != nullptr) {
+    float* e = a.fa + point * a.FA + a.W;
+    for (int c = 0; c < a.Xp; ++c) e[c] = 0.f;
+    for (int c = 0; c < 3; ++c) e[a.x_sun + c] = a.sun_d[(size_t)n * a.sun_stride + c];
+    if (a.t != nullptr)
+      for (int c = 0; c < a.tau; ++c) e[a.x_t + c] = a.t[(size_t)n * a.tau + c];
+    if (a.t_s != nullptr && a.x_ts >= 0)
+      for (int c = 0; c < a.tau; ++c) e[a.x_ts + c] = a.t_s[(size_t)n * a.tau + c];
+  }
+}
+
+int launch_encode(const EncodeArgs& a, hipStream_t st) {
+  const long long n = (long long)a.N * a.S * (a.F > 0 ? a.F : 1);
+  hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- parameter pack / gradient unpack ---------------------------------------------------------------
+__global__ void copy_table_kernel(CopyTable tb, float* __restrict__ packed, int mode) {
+  const CopyEntry e = tb.e[blockIdx.x];
+  const int total = e.rows * e.cols;
+  for (int idx = blockIdx.y * blockDim.x + threadIdx.x; idx < total; idx += gridDim.y * blockDim.x) {
+    const int r = idx / e.cols, c = idx - r * e.cols;
+    float* pk = packed + e.dst_off + (size_t)r * e.dst_ld + c;
+    float* us = e.user + (size_t)r * e.user_ld + c;
+    if (mode == 0) *pk = *us;          // pack: parameter tensor -> packed
+    else if (mode == 1) *us = *pk;     // unpack (overwrite)
+    else *us += *pk;                   // unpack (accumulate)
+  }
+}
+
+int launch_copy_table(const CopyTable& tb, float* packed, int mode, hipStream_t st) {
+  if (tb.n <= 0) return 0;
+  hipLaunchKernelGGL(copy_table_kernel, dim3(tb.n, 8), dim3(256), 0, st, tb, packed, mode);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- slab reductions ---------------------------------------------------------------------------------
+// out[g][j] (+)= sum_{q in group g} in[q][j]; deterministic (fixed order), no atomics.
+__global__ void reduce_rows_kernel(const float* __restrict__ in, int n_in, size_t in_stride, int width,
+                                   float* __restrict__ out, size_t out_stride, int group, int accumulate) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= width) return;
+  const int g = blockIdx.y;
+  const int q0 = g * group, q1 = min(n_in, q0 + group);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int q = q0;
+  for (; q + 3 < q1; q += 4) {
+    s0 += in[(size_t)(q + 0) * in_stride + j];
+    s1 += in[(size_t)(q + 1) * in_stride + j];
+    s2 += in[(size_t)(q + 2) * in_stride + j];
+    s3 += in[(size_t)(q + 3) * in_stride + j];
+  }
+  for (; q < q1; ++q) s0 += in[(size_t)q * in_stride + j];
+  const float s = (s0 + s1) + (s2 + s3);
+  float* o = out + (size_t)g * out_stride + j;
+  *o = accumulate ? (*o + s) : s;
+}
+
+int launch_reduce_rows(const float* in, int n_in, size_t in_stride, int width, float* out,
+                       size_t out_stride, int group, int accumulate, hipStream_t st) {
+  if (n_in <= 0 || width <= 0) return 0;
+  const int ng = (n_in + group - 1) / group;
+  hipLaunchKernelGGL(reduce_rows_kernel, dim3((width + 255) / 256, ng), dim3(256), 0, st, in, n_in, in_stride,
+                     width, out, out_stride, group, accumulate);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
+// two-level deterministic reduction of [n_in][stride] partials into out[width] (+=)
+int reduce_partials(const float* in, int n_in, size_t in_stride, int width, float* tmp, float* out,
+                    hipStream_t st) {
+  if (n_in <= 64) return launch_reduce_rows(in, n_in, in_stride, width, out, 0, n_in, 1, st);
+  const int group = (n_in + 63) / 64;
+  const int ng = (n_in + group - 1) / group;
+  int rc = launch_reduce_rows(in, n_in, in_stride, width, tmp, (size_t)width, group, 0, st);
+  if (rc) return rc;
+  return launch_reduce_rows(tmp, ng, (size_t)width, width, out, 0, ng, 1, st);
+}
+
+// column sums of a [rows][32] buffer -> partial[blocks][32] (1024 rows per block)
+__global__ void colsum32_kernel(const float* __restrict__ in, int rows, float* __restrict__ partial) {
+  __shared__ float sm[8][32];
+  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int r0 = blockIdx.x * 1024;
+  float s = 0.f;
+  for (int i = 0; i < 128; ++i) {
+    const int r = r0 + rg + 8 * i;
+    if (r < rows) s += in[(size_t)r * 32 + col];
+  }
+  sm[rg][col] = s;
+  __syncthreads();
+  if (rg == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += sm[i][col];
+    partial[blockIdx.x * 32 + col] = t;
+  }
+}
+
+int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st) {
+  hipLaunchKernelGGL(colsum32_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, in, rows, partial);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
+// d loss / d t[n][c] = sum_s dfa[(n*S+s)][col0 + c]   (gradient reaching the nn.Embedding rows)
+__global__ void ray_sum_kernel(const float* __restrict__ dfa, int ld, int col0, int N, int S, int tau,
+                               float* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= N * tau) return;
+  const int n = g / tau, c = g - n * tau;
+  const float* p = dfa + (size_t)n * S * ld + col0 + c;
+  float s = 0.f;
+  for (int j = 0; j < S; ++j) s += p[(size_t)j * ld];
+  out[g] = s;
+}
+
+int launch_ray_sum(const float* dfa, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(ray_sum_kernel, dim3((N * tau + 255) / 256), dim3(256), 0, st, dfa, ld, col0, N, S, tau, out);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace snerf

@@ -1,0 +1,78 @@
+// Shared device/host helpers for libsnerf_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace snerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+__host__ __device__ inline size_t round_up_sz(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// ---- elementwise math with the reference's semantics (torch defaults) ----------------------------
+// torch.nn.Softplus(beta=1, threshold=20): x if x > 20 else log1p(exp(x))
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+// d softplus / dx = sigmoid(x) (1 above the threshold)
+__device__ __forceinline__ float softplus_grad_f(float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+// Accurate sincos for SIREN / positional encoding arguments.
+// Cody-Waite reduction by pi/2 split in four parts (exact products for |k| < 2^15), then
+// minimax polynomials on [-pi/4, pi/4].  |x| <= ~3e4 stays below 2 ulp; larger arguments fall back to
+// the device library's Payne-Hanek path.  (The reference evaluates torch.sin on the ATen CPU/GPU
+// kernels, i.e. <= 1-2 ulp; hardware v_sin_f32 is NOT accurate enough once amplified by w0=30.)
+__device__ __forceinline__ void sincos_acc(float x, float* s, float* c) {
+  if (__builtin_expect(fabsf(x) > 30000.f, 0)) {
+    sincosf(x, s, c);
+    return;
+  }
+  const float kf = rintf(x * 0.63661977236758134308f);  // x * 2/pi
+  const int k = (int)kf;
+  // pi/2 = A + B + C + D; A and B carry few mantissa bits so kf*A, kf*B are exact for |kf| < 2^15
+  float r = fmaf(kf, -1.5703125f, x);
+  r = fmaf(kf, -4.837512969970703125e-4f, r);
+  r = fmaf(kf, -7.549790126404332e-08f, r);
+  r = fmaf(kf, 1.7151245100058819e-15f, r);
+  const float r2 = r * r;
+  // sin(r) = r + r^3 P(r^2), cos(r) = 1 - r^2/2 + r^4 Q(r^2) on |r| <= pi/4 (Chebyshev fits,
+  // fit error 2e-11 / 1e-12; measured on CPU in fp32: <= 1.55 ulp, 9.3e-8 abs for |x| <= 3e4)
+  float ps = fmaf(r2, 2.7237618203173253e-06f, -0.00019839989971755576f);
+  ps = fmaf(ps, r2, 0.00833333169215251f);
+  ps = fmaf(ps, r2, -0.16666666663377128f);
+  const float sr = fmaf(r * r2, ps, r);
+  float pc = fmaf(r2, -2.7290681713851145e-07f, 2.48005195681466e-05f);
+  pc = fmaf(pc, r2, -0.0013888887519541702f);
+  pc = fmaf(pc, r2, 0.04166666666392173f);
+  const float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+  const bool swap = k & 1;
+  float ss = swap ? cr : sr;
+  float cc = swap ? sr : cr;
+  if (k & 2) ss = -ss;
+  if ((k + 1) & 2) cc = -cc;
+  *s = ss;
+  *c = cc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace snerf
+
+// ---- host-side error plumbing ------------------------------------------------------------------
+namespace snerf {
+void set_error(const char* fmt, ...);
+}
+#define SNERF_HIP_CHECK(expr)                                                              \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      snerf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return SNERF_ERR_HIP;                                                                \
+    }                                                                                      \
+  } while (0)
+#define SNERF_LAUNCH_CHECK() SNERF_HIP_CHECK(hipGetLastError())

@@ -1,0 +1,39 @@
+// Tiled fp32-MFMA GEMM with fused prologue/epilogue: the one contraction kernel behind every layer
+// of the MLP (forward, dX and dW).  See gemm.hip for the kernel; DESIGN.md "Kernels" for the roofline.
+#pragma once
+#include "common.h"
+
+namespace snerf {
+
+enum GemmAct { ACT_NONE = 0, ACT_SIN = 1, ACT_RELU = 2 };
+enum GemmAux { AUX_NONE = 0, AUX_MUL = 1, AUX_RELU_MASK = 2 };
+
+// C[i, j] = epilogue( sum_k A(i,k) * B(j,k) )
+// Operand storage: "KC" (k-contiguous): element (i,k) at P[i*ld + k]; "IC" (i-contiguous): P[k*ld + i].
+struct GemmArgs {
+  // A operand. KC mode may be split in two k-segments ([0,Ka) from A, [Ka,K) from A2): skip-concat
+  // [gamma, h] of the trunk and [d feats | d sigma] of the backward pass without materialising the cat.
+  const float* A = nullptr;  int lda = 0;  int Ka = 0;
+  const float* A2 = nullptr; int lda2 = 0;
+  bool a_ic = false;
+  const float* B = nullptr;  int ldb = 0;  bool b_ic = false;
+  int I = 0, J = 0, K = 0;
+  float* C = nullptr; int ldc = 0;
+  // forward epilogue: + bias[j], activation; C2 (optional) receives w0*cos(w0*z) for the backward pass
+  const float* bias = nullptr;
+  int act = ACT_NONE;
+  float w0 = 1.f;
+  float* C2 = nullptr;
+  // backward epilogue: multiply by aux (saved activation derivative) or mask by aux > 0 (ReLU);
+  // colsum (optional): per-32-row partial column sums of the final values, [ceil(I/32)][ldcs] (bias grads)
+  const float* aux = nullptr; int ldaux = 0; int aux_mode = AUX_NONE;
+  float* colsum = nullptr; int ldcs = 0;
+  // split-K (dW): blockIdx.z = split s handles k in [s*k_split, (s+1)*k_split), writes C + s*slab_stride
+  int k_split = 0; int n_split = 1; size_t slab_stride = 0;
+  bool narrow_j = false;  // 128x32 tile (J <= 32-wide heads)
+  bool narrow_i = false;  // 32x128 tile (dW of the narrow heads)
+};
+
+int launch_gemm(const GemmArgs& g, hipStream_t stream);
+
+}  // namespace snerf

@@ -1,0 +1,62 @@
+// Host-side layout plan: packed parameter offsets and workspace regions derived from a SnerfDesc.
+// Everything the kernels index is computed here once per call, so host code can check every
+// operand shape before a launch (a faulting kernel can reset the node).
+#pragma once
+#include "common.h"
+#include "../../include/snerf_hip.h"
+
+namespace snerf {
+
+constexpr int NARROW = 32;   // padded width of the 1..(5+C)-wide head outputs
+constexpr int MAX_CLASSES = 16;
+constexpr int MAX_SKY_UNITS = 8;  // feat_last <= 512 (units per lane in the composite kernels)
+
+struct Plan {
+  // dims
+  int N = 0, S = 0, P = 0, Pp = 0;
+  int W = 0, H = 0, L = 0, E = 0, Ep = 0, F = 0, tau = 0, C = 0;
+  bool siren = false, train = false, sc = false, sem_sigmoid = false;
+  unsigned skip_mask = 0;
+  // extras columns appended to the feats buffer: [sun(3) | t(tau) | t_s(tau)] padded to 4
+  int x_sun = 0, x_t = 3, x_ts = -1, Xp = 0, FA = 0;
+  // first head layers fused into one GEMM: blocks of H rows; sun block last
+  int nblk = 0, blk_rgb = 0, blk_sem = -1, blk_beta = -1, blk_sbeta = -1, blk_sun = -1;
+  int N1 = 0;   // rows of the fused first-head-layer matrix
+  int KF = 0;   // contraction length of the block-diagonal final-layer matrix (all blocks but sun)
+  bool rgb_t = false, sem_t = false, sem_ts = false, sbeta_ts = false;
+  // final-layer output columns inside the NARROW-wide buffer
+  static constexpr int col_rgb = 0, col_beta = 3, col_sbeta = 4, col_sem = 5;
+
+  // packed parameter layout (float offsets). weights: row-major [rows][ld]
+  size_t w_tr[SNERF_MAX_LAYERS] = {0}, b_tr[SNERF_MAX_LAYERS] = {0};
+  int k_tr[SNERF_MAX_LAYERS] = {0};
+  size_t w_fs = 0, b_fs = 0;        // [W + NARROW][W]: feats rows then sigma row
+  size_t w_h1 = 0, b_h1 = 0;        // [N1][FA]
+  size_t w_s2 = 0, b_s2 = 0, w_s3 = 0, b_s3 = 0;  // [H][H]
+  size_t w_s4 = 0, b_s4 = 0;        // [NARROW][H], row 0 used
+  size_t w_fin = 0, b_fin = 0;      // [NARROW][KF]
+  size_t sky = 0;                   // [H][4] w0 | [H] b0 | [4][H] w2 | [4] b2
+  int sky_floats = 0;
+  size_t packed_floats = 0;
+
+  // workspace layout (byte offsets)
+  size_t o_z = 0, o_T = 0, o_rgbraw = 0, o_pe = 0, o_fa = 0, o_h1 = 0, o_c1 = 0;
+  size_t o_h[SNERF_MAX_LAYERS] = {0}, o_c[SNERF_MAX_LAYERS] = {0};
+  size_t o_s2 = 0, o_s3 = 0, o_cs2 = 0, o_cs3 = 0;
+  size_t o_sigo = 0, o_fino = 0, o_suno = 0;
+  // backward scratch
+  size_t o_dza = 0, o_dzb = 0, o_dsa = 0, o_dsb = 0, o_dsig = 0, o_dfin = 0, o_dsun = 0;
+  size_t o_colsum = 0, o_colsum2 = 0, o_slab = 0, o_skyslab = 0;
+  int h1w = 0;       // width of the h1 buffer in this pass (N1, or H for the sc pass)
+  int maxw = 0;      // widest dz buffer
+  int n_split = 1, k_split = 32;  // dW split-K
+  int nrb = 0;       // 32-row blocks (colsum partials)
+  int comp_blocks = 0;
+  size_t slab_floats = 0;
+  size_t ws_bytes = 0;
+};
+
+// returns SNERF_OK or an error (message via set_error)
+int make_plan(const SnerfDesc* d, Plan* pl);
+
+}  // namespace snerf

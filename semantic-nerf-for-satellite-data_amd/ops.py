@@ -1,0 +1,305 @@
+"""torch <-> C-ABI glue for one rendering pass: descriptor, parameter packing, autograd.Function.
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); all arithmetic of the hot
+path runs in libsnerf_hip.so.  There is no fallback: a CPU tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib
+
+# parameter names in the reference's state_dict order -> SnerfParams field
+_HEAD_FIELDS = {
+    "sigma_from_xyz.0.weight": "sigma_w", "sigma_from_xyz.0.bias": "sigma_b",
+    "feats_from_xyz.weight": "feats_w", "feats_from_xyz.bias": "feats_b",
+    "rgb_from_xyzdir.0.weight": "rgb_w0", "rgb_from_xyzdir.0.bias": "rgb_b0",
+    "rgb_from_xyzdir.2.weight": "rgb_w2", "rgb_from_xyzdir.2.bias": "rgb_b2",
+    "semantic_prediction.0.weight": "sem_w0", "semantic_prediction.0.bias": "sem_b0",
+    "semantic_prediction.2.weight": "sem_w2", "semantic_prediction.2.bias": "sem_b2",
+    "sky_color.0.weight": "sky_w0", "sky_color.0.bias": "sky_b0",
+    "sky_color.2.weight": "sky_w2", "sky_color.2.bias": "sky_b2",
+    "beta_from_xyz.0.weight": "beta_w0", "beta_from_xyz.0.bias": "beta_b0",
+    "beta_from_xyz.2.weight": "beta_w2", "beta_from_xyz.2.bias": "beta_b2",
+    "semantic_beta_from_xyz.0.weight": "sbeta_w0", "semantic_beta_from_xyz.0.bias": "sbeta_b0",
+    "semantic_beta_from_xyz.2.weight": "sbeta_w2", "semantic_beta_from_xyz.2.bias": "sbeta_b2",
+}
+
+
+@dataclass(frozen=True)
+class ModelSpec:
+    """Architecture part of SnerfDesc (field names: configs/pipelines/rs_semantic.toml:13-67)."""
+    fc_units: int = 512
+    fc_layers: int = 8
+    feat_last: int = 256
+    fc_skips: tuple = (4,)
+    n_freq: int = 10            # mapping_pos_n_freq; 0 = identity (baseline SatNeRF)
+    siren: bool = True
+    t_dim: int = 4
+    n_classes: int = 5          # 0 = baseline SatNeRF
+    sem_sigmoid: bool = True
+    use_tj_instead_of_beta: bool = False
+    use_tj_for_s: bool = False
+    use_separate_beta_for_s: bool = False
+    use_separate_tj_for_semantic: bool = False
+
+    @staticmethod
+    def from_pipeline_cfg(pc, n_classes: int, model: str = "semantic") -> "ModelSpec":
+        sem = model == "semantic"
+        W = pc.fc_units
+        return ModelSpec(
+            fc_units=W, fc_layers=pc.fc_layers, feat_last=W if pc.fc_use_full_features else W // 2,
+            fc_skips=tuple(pc.fc_skips), n_freq=pc.mapping_pos_n_freq if sem else 0,
+            siren=pc.activation_function == "siren", t_dim=pc.t_embedding_tau,
+            n_classes=n_classes if sem else 0,
+            sem_sigmoid=sem and getattr(pc, "semantic_activation_function", "sigmoid") == "sigmoid",
+            use_tj_instead_of_beta=sem and bool(getattr(pc, "use_tj_instead_of_beta", False)),
+            use_tj_for_s=sem and bool(getattr(pc, "use_tj_for_s", False)),
+            use_separate_beta_for_s=sem and bool(getattr(pc, "use_separate_beta_for_s", False)),
+            use_separate_tj_for_semantic=sem and bool(getattr(pc, "use_separate_tj_for_semantic", False)))
+
+    def desc(self, n_rays: int, n_samples: int, flags: int = 0) -> _lib.SnerfDesc:
+        mask = 0
+        for s in self.fc_skips:
+            mask |= 1 << int(s)
+        return _lib.SnerfDesc(
+            n_rays=n_rays, n_samples=n_samples, fc_units=self.fc_units, fc_layers=self.fc_layers,
+            feat_last=self.feat_last, skip_mask=mask, n_freq=self.n_freq, siren=int(self.siren), t_dim=self.t_dim,
+            n_classes=self.n_classes, sem_sigmoid=int(self.sem_sigmoid),
+            use_tj_instead_of_beta=int(self.use_tj_instead_of_beta), use_tj_for_s=int(self.use_tj_for_s),
+            use_separate_beta_for_s=int(self.use_separate_beta_for_s),
+            use_separate_tj_for_semantic=int(self.use_separate_tj_for_semantic), flags=flags)
+
+    def param_names(self) -> list:
+        names = []
+        for i in range(self.fc_layers):
+            names += [f"fc_net.{2 * i}.weight", f"fc_net.{2 * i}.bias"]
+        names += ["sigma_from_xyz.0.weight", "sigma_from_xyz.0.bias", "feats_from_xyz.weight", "feats_from_xyz.bias",
+                  "rgb_from_xyzdir.0.weight", "rgb_from_xyzdir.0.bias", "rgb_from_xyzdir.2.weight",
+                  "rgb_from_xyzdir.2.bias"]
+        if self.n_classes > 0:
+            names += ["semantic_prediction.0.weight", "semantic_prediction.0.bias", "semantic_prediction.2.weight",
+                      "semantic_prediction.2.bias"]
+        for j in (0, 2, 4, 6):
+            names += [f"sun_v_net.{j}.weight", f"sun_v_net.{j}.bias"]
+        names += ["sky_color.0.weight", "sky_color.0.bias", "sky_color.2.weight", "sky_color.2.bias",
+                  "beta_from_xyz.0.weight", "beta_from_xyz.0.bias", "beta_from_xyz.2.weight", "beta_from_xyz.2.bias"]
+        if self.n_classes > 0 and self.use_separate_beta_for_s:
+            names += ["semantic_beta_from_xyz.0.weight", "semantic_beta_from_xyz.0.bias",
+                      "semantic_beta_from_xyz.2.weight", "semantic_beta_from_xyz.2.bias"]
+        return names
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_dev(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"snerf_amd: '{name}' must live on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"snerf_amd: '{name}' must be float32, got {t.dtype}")
+
+
+def params_struct(spec: ModelSpec, tensors: dict) -> _lib.SnerfParams:
+    ps = _lib.SnerfParams()
+    for name in spec.param_names():
+        t = tensors[name]
+        _check_dev(t, name)
+        if not t.is_contiguous():
+            raise RuntimeError(f"snerf_amd: parameter '{name}' must be contiguous")
+        if name.startswith("fc_net."):
+            i = int(name.split(".")[1]) // 2
+            (ps.fc_w if name.endswith("weight") else ps.fc_b)[i] = t.data_ptr()
+        elif name.startswith("sun_v_net."):
+            j = int(name.split(".")[1]) // 2
+            (ps.sun_w if name.endswith("weight") else ps.sun_b)[j] = t.data_ptr()
+        else:
+            setattr(ps, _HEAD_FIELDS[name], t.data_ptr())
+    return ps
+
+
+def pack_params(spec: ModelSpec, tensors: dict) -> torch.Tensor:
+    """state_dict tensors -> packed MFMA-friendly buffer (snerf_pack_params)."""
+    L = _lib.lib()
+    d = spec.desc(1, 1)
+    n = L.snerf_packed_floats(C.byref(d))
+    if n == 0:
+        _lib.check(1, "snerf_packed_floats")
+    dev = tensors[spec.param_names()[0]].device
+    packed = torch.empty(n, dtype=torch.float32, device=dev)
+    ps = params_struct(spec, tensors)
+    with torch.cuda.device(dev):
+        _lib.check(L.snerf_pack_params(C.byref(d), C.byref(ps), _ptr(packed), _stream()), "snerf_pack_params")
+    return packed
+
+
+def unpack_grads(spec: ModelSpec, packed_grads: torch.Tensor, like: dict, accumulate_into: dict | None = None) -> dict:
+    """packed gradient buffer -> dict name -> gradient tensor shaped like the parameters."""
+    L = _lib.lib()
+    d = spec.desc(1, 1)
+    if accumulate_into is None:
+        grads = {n: torch.empty_like(like[n]) for n in spec.param_names()}
+    else:
+        grads = accumulate_into
+    ps = params_struct(spec, grads)
+    with torch.cuda.device(packed_grads.device):
+        _lib.check(L.snerf_unpack_grads(C.byref(d), _ptr(packed_grads), C.byref(ps), int(accumulate_into is not None),
+                                        _stream()), "snerf_unpack_grads")
+    return grads
+
+
+@dataclass
+class PassInputs:
+    """One ray batch in either of the two seams (renderer: rays [+u]; inference(): xyz + z_vals)."""
+    sun_d: torch.Tensor                   # (N,3) (may be a strided view into extras (N,4))
+    rays: torch.Tensor | None = None      # (N,8)
+    xyz: torch.Tensor | None = None       # (N,S,3)
+    z_vals: torch.Tensor | None = None    # (N,S)
+    z_steps: torch.Tensor | None = None   # (S)
+    u: torch.Tensor | None = None         # (N,S)
+    _keep: list = field(default_factory=list)
+
+    def struct(self, t, t_s):
+        si = _lib.SnerfInputs()
+        for name in ("rays", "xyz", "z_vals", "z_steps", "u"):
+            v = getattr(self, name)
+            if v is not None:
+                _check_dev(v, name)
+                v = v.contiguous()
+                self._keep.append(v)
+                setattr(si, name, v.data_ptr())
+        sd = self.sun_d
+        _check_dev(sd, "sun_d")
+        if sd.dim() != 2 or sd.shape[1] != 3 or sd.stride(1) != 1:
+            sd = sd.contiguous()
+        self._keep.append(sd)
+        si.sun_d = sd.data_ptr()
+        si.sun_stride = sd.stride(0) if sd.shape[0] > 1 else 3
+        si.t = t.data_ptr()
+        si.t_s = t_s.data_ptr() if t_s is not None else None
+        return si
+
+
+_OUT_SHAPES = {
+    "rgb": lambda N, S, C: (N, 3), "depth": lambda N, S, C: (N,), "weights": lambda N, S, C: (N, S),
+    "transparency": lambda N, S, C: (N, S), "albedo": lambda N, S, C: (N, S, 3), "sun": lambda N, S, C: (N, S, 1),
+    "sky": lambda N, S, C: (N, S, 3), "beta": lambda N, S, C: (N, S, 1), "sigmas": lambda N, S, C: (N, S),
+    "beta_semantic": lambda N, S, C: (N, S, 1), "semantic_logits": lambda N, S, C: (N, C),
+}
+
+
+def output_keys(spec: ModelSpec, sc_pass: bool) -> list:
+    if sc_pass:
+        return ["weights", "transparency", "sun"]
+    keys = ["rgb", "depth", "weights", "transparency", "albedo", "sun", "sky", "beta", "sigmas"]
+    if spec.n_classes > 0:
+        if spec.use_separate_beta_for_s:
+            keys.append("beta_semantic")
+        keys.append("semantic_logits")
+    return keys
+
+
+class _RenderPass(torch.autograd.Function):
+    """forward = snerf_forward, backward = snerf_backward (+ snerf_unpack_grads)."""
+
+    @staticmethod
+    def forward(ctx, spec, pin, sc_pass, packed, names, t, t_s, *params):
+        L = _lib.lib()
+        N = t.shape[0]
+        S = (pin.z_vals.shape[1] if pin.z_vals is not None else
+             (pin.u.shape[1] if pin.u is not None else pin.z_steps.shape[0]))
+        dev = t.device
+        need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or t.requires_grad
+                                                 or (t_s is not None and t_s.requires_grad))
+        flags = (_lib.FLAG_TRAIN if need_grad else 0) | (_lib.FLAG_SC_PASS if sc_pass else 0)
+        d = spec.desc(N, S, flags)
+        nbytes = L.snerf_workspace_bytes(C.byref(d))
+        if nbytes == 0:
+            _lib.check(1, "snerf_workspace_bytes")
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        keys = output_keys(spec, sc_pass)
+        outs = {k: torch.empty(_OUT_SHAPES[k](N, S, spec.n_classes), dtype=torch.float32, device=dev) for k in keys}
+        label = torch.empty((N,), dtype=torch.int64, device=dev) if (spec.n_classes > 0 and not sc_pass) else None
+        z_out = torch.empty((N, S), dtype=torch.float32, device=dev)
+        so = _lib.SnerfOutputs()
+        for k, v in outs.items():
+            setattr(so, k, v.data_ptr())
+        so.semantic_label = label.data_ptr() if label is not None else None
+        so.z_vals = z_out.data_ptr()
+        _check_dev(t, "t")
+        tc = t.contiguous()
+        tsc = t_s.contiguous() if t_s is not None else None
+        si = pin.struct(tc, tsc)
+        with torch.cuda.device(dev):
+            _lib.check(L.snerf_forward(C.byref(d), _ptr(packed), C.byref(si), C.byref(so), _ptr(ws), nbytes,
+                                       _stream()), "snerf_forward")
+        ctx.spec, ctx.pin, ctx.desc, ctx.ws, ctx.nbytes = spec, pin, d, ws, nbytes
+        ctx.packed, ctx.names, ctx.keys, ctx.tc, ctx.tsc = packed, names, keys, tc, tsc
+        ctx.param_like = params
+        ctx.train = need_grad
+        ret = tuple(outs[k] for k in keys)
+        nd = [z_out] + ([label] if label is not None else [])
+        ctx.mark_non_differentiable(*nd)
+        ctx.n_diff = len(keys)
+        return ret + tuple(nd)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        L = _lib.lib()
+        if not ctx.train:
+            raise RuntimeError("snerf_amd: backward through a pass that was run without SNERF_FLAG_TRAIN")
+        spec, d = ctx.spec, ctx.desc
+        go = _lib.SnerfOutGrads()
+        keep = []
+        for k, g in zip(ctx.keys, gouts[:ctx.n_diff]):
+            if g is not None:
+                g = g.contiguous()
+                keep.append(g)
+                setattr(go, k, g.data_ptr())
+        dev = ctx.tc.device
+        pg = torch.zeros_like(ctx.packed)
+        d_t = torch.empty_like(ctx.tc)
+        d_ts = torch.empty_like(ctx.tsc) if ctx.tsc is not None else None
+        si = ctx.pin.struct(ctx.tc, ctx.tsc)
+        with torch.cuda.device(dev):
+            _lib.check(L.snerf_backward(C.byref(d), _ptr(ctx.packed), C.byref(si), C.byref(go), _ptr(pg), _ptr(d_t),
+                                        _ptr(d_ts), _ptr(ctx.ws), ctx.nbytes, _stream()), "snerf_backward")
+        like = dict(zip(ctx.names, ctx.param_like))
+        grads = unpack_grads(spec, pg, like)
+        ctx.ws = None
+        return (None, None, None, None, None, d_t, d_ts) + tuple(grads[n] for n in ctx.names)
+
+
+def render_pass(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Tensor, t_s: torch.Tensor | None = None,
+                sc_pass: bool = False, packed: torch.Tensor | None = None) -> dict:
+    """Run one pass (main, or the solar-correction variant) and return the reference's result dict
+    (semantic/models/rs_semantic.py:111-128) plus 'z_vals'."""
+    names = spec.param_names()
+    plist = [params[n] for n in names]
+    if packed is None:
+        packed = pack_params(spec, params)
+    res = _RenderPass.apply(spec, pin, sc_pass, packed, names, t, t_s, *plist)
+    keys = output_keys(spec, sc_pass)
+    out = dict(zip(keys, res[:len(keys)]))
+    out["z_vals"] = res[len(keys)]
+    if len(res) > len(keys) + 1:
+        out["semantic_label"] = res[len(keys) + 1]
+    return out
+
+
+def test_gemm(A: torch.Tensor, B: torch.Tensor, a_ic: bool, b_ic: bool, I: int, J: int, K: int, narrow: int = 0):
+    """C[I,J] = sum_k A(i,k) B(j,k) through the library's tiled MFMA kernel (test hook)."""
+    L = _lib.lib()
+    Cm = torch.full((I, J), float("nan"), dtype=torch.float32, device=A.device)
+    with torch.cuda.device(A.device):
+        _lib.check(L.snerf_test_gemm(_ptr(A), A.stride(0), int(a_ic), _ptr(B), B.stride(0), int(b_ic), _ptr(Cm), J,
+                                     I, J, K, narrow, _stream()), "snerf_test_gemm")
+    return Cm
