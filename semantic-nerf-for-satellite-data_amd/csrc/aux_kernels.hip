@@ -7,8 +7,21 @@ namespace snerf {
 // ---- stratified sampling: z = lower + (upper - lower) * u ------------------------------------------
 // framework/components/rendering.py:95-110.  Every product/sum is rounded separately (no FMA
 // contraction) so z is bit-identical to the reference's chain of elementwise ATen ops.
+// NB: HIP's *_rn float intrinsics are plain operators and hipcc contracts a*b+c into an FMA by
+// default (-ffp-contract=fast), so contraction is switched off per function here.
+__device__ __forceinline__ float mul_nofma(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float add_nofma(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
 __device__ __forceinline__ float z_lin(float near, float far, float s) {
-  return __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, s)), __fmul_rn(far, s));
+#pragma clang fp contract(off)
+  const float a = near * (1.f - s);
+  const float b = far * s;
+  return a + b;
 }
 
 __global__ void sample_z_kernel(const float* __restrict__ rays, const float* __restrict__ zsteps,
@@ -21,9 +34,9 @@ __global__ void sample_z_kernel(const float* __restrict__ rays, const float* __r
   float out = zj;
   if (u != nullptr) {
     float lower = zj, upper = zj;
-    if (j > 0) lower = __fmul_rn(0.5f, __fadd_rn(z_lin(near, far, zsteps[j - 1]), zj));
-    if (j < S - 1) upper = __fmul_rn(0.5f, __fadd_rn(zj, z_lin(near, far, zsteps[j + 1])));
-    out = __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u[g]));
+    if (j > 0) lower = mul_nofma(0.5f, add_nofma(z_lin(near, far, zsteps[j - 1]), zj));
+    if (j < S - 1) upper = mul_nofma(0.5f, add_nofma(zj, z_lin(near, far, zsteps[j + 1])));
+    out = add_nofma(lower, mul_nofma(add_nofma(upper, -lower), u[g]));
   }
   z[g] = out;
 }
@@ -58,7 +71,7 @@ __global__ void encode_kernel(EncodeArgs a) {
     } else {
       const float o = a.rays[n * 8 + c];
       const float d = a.dir_is_sun ? a.sun_d[(size_t)n * a.sun_stride + c] : a.rays[n * 8 + 3 + c];
-      x[c] = __fadd_rn(o, __fmul_rn(d, a.z[point]));
+      x[c] = add_nofma(o, mul_nofma(d, a.z[point]));
     }
   }
   float* pe = a.pe + point * a.Ep;

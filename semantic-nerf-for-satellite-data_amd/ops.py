@@ -211,14 +211,12 @@ class _RenderPass(torch.autograd.Function):
     """forward = snerf_forward, backward = snerf_backward (+ snerf_unpack_grads)."""
 
     @staticmethod
-    def forward(ctx, spec, pin, sc_pass, packed, names, t, t_s, *params):
+    def forward(ctx, spec, pin, sc_pass, need_grad, packed, names, t, t_s, *params):
         L = _lib.lib()
         N = t.shape[0]
         S = (pin.z_vals.shape[1] if pin.z_vals is not None else
              (pin.u.shape[1] if pin.u is not None else pin.z_steps.shape[0]))
         dev = t.device
-        need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in params) or t.requires_grad
-                                                 or (t_s is not None and t_s.requires_grad))
         flags = (_lib.FLAG_TRAIN if need_grad else 0) | (_lib.FLAG_SC_PASS if sc_pass else 0)
         d = spec.desc(N, S, flags)
         nbytes = L.snerf_workspace_bytes(C.byref(d))
@@ -275,7 +273,7 @@ class _RenderPass(torch.autograd.Function):
         like = dict(zip(ctx.names, ctx.param_like))
         grads = unpack_grads(spec, pg, like)
         ctx.ws = None
-        return (None, None, None, None, None, d_t, d_ts) + tuple(grads[n] for n in ctx.names)
+        return (None, None, None, None, None, None, d_t, d_ts) + tuple(grads[n] for n in ctx.names)
 
 
 def render_pass(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Tensor, t_s: torch.Tensor | None = None,
@@ -286,7 +284,10 @@ def render_pass(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Tensor,
     plist = [params[n] for n in names]
     if packed is None:
         packed = pack_params(spec, params)
-    res = _RenderPass.apply(spec, pin, sc_pass, packed, names, t, t_s, *plist)
+    # grad mode is always off inside Function.forward, so decide here whether activations are kept
+    need_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in plist) or t.requires_grad
+                                             or (t_s is not None and t_s.requires_grad))
+    res = _RenderPass.apply(spec, pin, sc_pass, need_grad, packed, names, t, t_s, *plist)
     keys = output_keys(spec, sc_pass)
     out = dict(zip(keys, res[:len(keys)]))
     out["z_vals"] = res[len(keys)]
