@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train rays/s of the semantic Sat-NeRF hot path on synthetic ray batches.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one full optimiser step of BASELINE.json configs[1] ("JAX_068 semantic pipeline, 4096 rays x 64
+samples, fp32") per GPU: on-device batch sampling -> main + solar-correction forward -> SatNerfLoss +
+solar correction + SemanticLoss (fused HIP loss kernels) -> backward -> flat gradient all-reduce (RCCL,
+N > 1) -> Adam.  Weak scaling: 4096 rays per GPU.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FLOPS_PER_SAMPLE_TRAIN = 31_453_696  # main 3*F_m + sc (F_s + 2*F_s-branch), fc_units=512
+FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def make_cfgs(rays_per_gpu, samples, world):
+    from snerf_amd.framework.configs import MainConfig
+    pipeline = {
+        "pipeline": "snerf_amd.semantic.pipelines.rs_semantic.RSSemanticPipeline",
+        # configs/pipelines/rs_semantic.toml values
+        "n_samples": samples, "batch_size": rays_per_gpu * world, "render_chunk_size": 1 << 22,
+        "learnrate": 5e-4, "fc_units": 512, "fc_layers": 8, "fc_skips": [4], "activation_function": "siren",
+        "mapping_pos_n_freq": 10, "sc_lambda": 0.05, "t_embedding_vocab": 50, "t_embedding_tau": 4,
+        "lambda_s": 0.04, "semantic_activation_function": "sigmoid", "ignore_car_index": True,
+        # steady state of training: beta loss active (epoch >= first_beta_epoch), depth rays dropped
+        # (after 25 % of the steps, baseline/pipelines/satnerf.py:26-29) -- SURVEY.md 8(d)
+        "first_beta_epoch": 0, "depth_enabled": False,
+    }
+    run = {"max_train_steps": 1 << 30, "synthetic_rays": max(1 << 20, rays_per_gpu * world * 4), "synthetic_images": 19,
+           "synthetic_seed": 0, "shuffle_dataset": True}
+    return MainConfig(run=run, pipeline=pipeline)
+
+
+def cpu_baseline(samples, seconds_budget=25.0):
+    """The CPU oracle (oracle/snerf_oracle.py, the restatement pinned to the reference by golden vectors)
+    timed on the host cores on a bounded sample of the same workload: full train step, W=512."""
+    from oracle import snerf_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    cfg = O.OracleCfg(n_samples=samples)
+    n = 256
+    p = O.to_torch(O.init_params_numpy(cfg, 0), requires_grad=True)
+    emb = torch.from_numpy(O.init_embedding_numpy(cfg, 0)).requires_grad_(True)
+    b = O.batch_to_torch(O.synthetic_batch(n, samples, seed=0))
+    O.train_step(p, emb, cfg, b, epoch=2)  # warm-up
+    t0 = time.time()
+    reps = 0
+    while reps < 1 or (time.time() - t0) < seconds_budget / 2 and reps < 8:
+        O.train_step(p, emb, cfg, b, epoch=2)
+        reps += 1
+    dt = (time.time() - t0) / reps
+    return {"value": n / dt, "unit": "train rays/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} full train steps (main+sc fwd, losses, bwd) of {n} rays x {samples} samples, "
+                      f"fc_units=512, oracle/snerf_oracle.py on torch CPU fp32, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU")
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-GEMM HIP-event timing")
+    args = ap.parse_args()
+
+    import snerf_amd  # noqa: F401
+    from snerf_amd import _lib, parallel
+    from snerf_amd.framework.pipelines import load_pipeline, TrainLoop
+
+    rank, world, device = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    L = _lib.lib()
+    torch.manual_seed(0)
+    cfgs = make_cfgs(args.rays, args.samples, world)
+    pipe = load_pipeline(cfgs)
+    pipe.log_metrics = False  # the reference logs per-step scalars lazily; no host sync inside the timed region
+    loop = TrainLoop(pipe, cfgs, device)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        loop.step(step)
+        step += 1
+    barrier()
+    prof = None
+    if not args.no_profile:
+        L.snerf_profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = loop.step(step)
+        step += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if not args.no_profile:
+        prof = _lib.SnerfProfile()
+        _lib.check(L.snerf_profile_end(C.byref(prof)), "snerf_profile_end")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss = float(out["loss"].detach())
+
+    if rank != 0:
+        return
+    rays_total = args.rays * world * args.steps
+    value = rays_total / dt
+    flops_step_gpu = FLOPS_PER_SAMPLE_TRAIN * args.rays * args.samples
+    line = {
+        "metric": "train rays/sec (4096 rays x 64 samples)", "value": value, "unit": "rays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "JAX_068 semantic pipeline (configs[1]): RSSemanticNeRF fc_units=512 x 8 layers, C=5, "
+                               f"{args.rays} rays x {args.samples} samples per GPU, fp32, main + solar-correction pass, "
+                               "SatNerfLoss + sc + SemanticLoss(ignore car), Adam lr 5e-4; synthetic rays (SURVEY 8d), "
+                               "random-init SIREN weights",
+                   "rays_per_gpu": args.rays, "samples": args.samples, "global_batch": args.rays * world,
+                   "parallelism": f"dp{world}", "final_loss": loss},
+    }
+    step_tflops = flops_step_gpu * args.steps / dt / 1e12  # per GPU, algorithmic (SURVEY 8d figure)
+    if prof is not None:
+        ms = sum(prof.ms[v] for v in range(3))
+        fl = sum(prof.flops[v] for v in range(3))
+        n = sum(prof.launches[v] for v in range(3))
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        line["roofline"] = {
+            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": "snerf::gemm_kernel<128,128,64,64,*,*> (v_mfma_f32_32x32x2_f32), all three operand-layout instantiations",
+            "launches": int(n), "avg_launch_ms": ms / max(n, 1), "gemm_ms_per_step": ms / args.steps,
+            "per_variant": {(_lib.PROFILE_VARIANTS[v]): {
+                "launches": int(prof.launches[v]), "avg_ms": prof.ms[v] / max(prof.launches[v], 1),
+                "tflops": (prof.flops[v] / (prof.ms[v] * 1e-3) / 1e12) if prof.ms[v] > 0 else 0.0} for v in range(4)},
+            "whole_step_algorithmic_tflops": step_tflops, "whole_step_frac": step_tflops / FP32_MFMA_PEAK_TFLOPS,
+        }
+    else:
+        line["roofline"] = {"bound": "mfma", "achieved": step_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": step_tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                            "kernel": "whole step (algorithmic FLOPs / wall time); per-kernel timing disabled"}
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args.samples)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -161,6 +161,77 @@ int snerf_backward(const SnerfDesc* desc, const float* packed_params, const Sner
                    const SnerfOutGrads* gout, float* packed_grads, float* d_t, float* d_t_s,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fused losses ---------------------------------------------------------------------------------
+ * Replaces SNerfLoss / SatNerfLoss / uncertainty_aware_loss / solar_correction / DepthLoss
+ * (baseline/components/loss.py:4-94), SemanticLoss / SemanticUncertaintyLoss / SemanticCarRegLoss
+ * (semantic/components/loss.py:6-157) and their autograd backward.  Two phases because the means have
+ * data-dependent denominators (CE over non-ignored rays, L_t over car rays): phase 1 reduces per-ray
+ * sums and counts into totals[SNERF_LOSS_NTOT]; under data parallelism the host all-reduces that small
+ * vector; phase 2 turns totals into the loss_dict values and d loss / d result tensors. */
+#define SNERF_LOSS_NTOT 16
+#define SNERF_LOSS_NTERMS 8
+/* indices into terms[]: the reference's loss_dict keys */
+#define SNERF_TERM_COLOR 0            /* coarse_color */
+#define SNERF_TERM_LOGBETA 1          /* coarse_logbeta */
+#define SNERF_TERM_SC2 2              /* coarse_sc_term2 */
+#define SNERF_TERM_SC3 3              /* coarse_sc_term3 */
+#define SNERF_TERM_SEMANTIC 4         /* coarse_semantic */
+#define SNERF_TERM_SEMANTIC_LOGBETA 5 /* coarse_semantic_logbeta */
+#define SNERF_TERM_CAR_REG 6          /* coarse_car_reg_loss */
+#define SNERF_TERM_DS 7               /* coarse_ds */
+
+typedef struct SnerfLossCfg {
+  int32_t n_rays, n_samples, n_classes;
+  int32_t color_mode;        /* 0 none, 1 SNerfLoss (plain MSE), 2 SatNerfLoss (beta-weighted + log beta) */
+  int32_t has_sc;            /* solar-correction terms (needs the *_sc inputs) */
+  int32_t sem_mode;          /* 0 none, 1 SemanticLoss, 2 SemanticUncertaintyLoss */
+  int32_t ignore_index;      /* CrossEntropyLoss ignore_index: car index, or -100 */
+  int32_t use_sbeta;         /* beta_semantic given (use_separate_beta_for_s) */
+  int32_t detach_beta_for_s;
+  int32_t car_reg;           /* SemanticCarRegLoss */
+  int32_t car_label;
+  int32_t has_depth;         /* DepthLoss on `depth` */
+  float sc_lambda, lambda_s, lambda_c, ds_lambda;
+} SnerfLossCfg;
+
+typedef struct SnerfLossIn {
+  const float* rgb; const float* weights; const float* beta; const float* beta_semantic;
+  const float* semantic_logits;
+  const float* sun_sc; const float* transparency_sc; const float* weights_sc;
+  const float* depth;
+  const float* gt_rgb;            /* (N,3) */
+  const int64_t* labels;          /* (N) */
+  const uint8_t* mask;            /* (N) bool, NULL = all rays (semantic_sparsity_mask) */
+  const float* gt_depth;          /* (N) */
+  const float* depth_weights;     /* (N) or NULL = 1 (ds_noweights) */
+} SnerfLossIn;
+
+typedef struct SnerfLossGrads { /* any may be NULL */
+  float* rgb; float* weights; float* beta; float* beta_semantic; float* semantic_logits; float* sun_sc; float* depth;
+} SnerfLossGrads;
+
+size_t snerf_loss_workspace_bytes(const SnerfLossCfg* cfg);
+int snerf_loss_partial(const SnerfLossCfg* cfg, const SnerfLossIn* in, float* totals, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* n_rays_global = number of rays the means run over (sum over ranks); grads are scaled by grad_scale */
+int snerf_loss_finish(const SnerfLossCfg* cfg, const SnerfLossIn* in, const float* totals, float n_rays_global,
+                      float grad_scale, float* terms, const SnerfLossGrads* grads, void* stream);
+
+/* ---- measurement hook ----------------------------------------------------------------------------
+ * Between snerf_profile_begin and snerf_profile_end every GEMM launch is bracketed by HIP events on the
+ * stream it is launched on; _end synchronises those events and returns, per kernel variant, the summed
+ * device time, the algorithmic FLOPs (2*I*J*K of each launch) and the launch count.
+ * variant 0: gemm_kernel<128,128,64,64,false,false> (forward X.W^T), 1: <..,false,true> (dX = dZ.W),
+ *         2: <..,true,true> (dW = dZ^T.X, split-K), 3: the 32-wide head variants. */
+#define SNERF_PROFILE_VARIANTS 4
+typedef struct SnerfProfile {
+  double ms[SNERF_PROFILE_VARIANTS];
+  double flops[SNERF_PROFILE_VARIANTS];
+  int64_t launches[SNERF_PROFILE_VARIANTS];
+} SnerfProfile;
+int snerf_profile_begin(void);
+int snerf_profile_end(SnerfProfile* out);
+
 /* ---- test hook: the tiled fp32-MFMA GEMM used by every layer --------------------------------------
  * C[I,J] = sum_k A(i,k) * B(j,k);  a_ic/b_ic = 0: operand stored (rows, K) K-contiguous,
  * 1: stored (K, rows) row-contiguous.  Exposed so tests can check the MFMA tiling in isolation. */

@@ -52,6 +52,36 @@ class SnerfOutGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in GRAD_FIELDS]
 
 
+class SnerfLossCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_rays", "n_samples", "n_classes", "color_mode", "has_sc", "sem_mode",
+                                          "ignore_index", "use_sbeta", "detach_beta_for_s", "car_reg", "car_label",
+                                          "has_depth")] + [(n, C.c_float) for n in (
+                                              "sc_lambda", "lambda_s", "lambda_c", "ds_lambda")]
+
+
+LOSS_IN_FIELDS = ("rgb", "weights", "beta", "beta_semantic", "semantic_logits", "sun_sc", "transparency_sc",
+                  "weights_sc", "depth", "gt_rgb", "labels", "mask", "gt_depth", "depth_weights")
+LOSS_GRAD_FIELDS = ("rgb", "weights", "beta", "beta_semantic", "semantic_logits", "sun_sc", "depth")
+LOSS_NTOT = 16
+LOSS_TERMS = ("coarse_color", "coarse_logbeta", "coarse_sc_term2", "coarse_sc_term3", "coarse_semantic",
+              "coarse_semantic_logbeta", "coarse_car_reg_loss", "coarse_ds")
+
+
+class SnerfLossIn(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in LOSS_IN_FIELDS]
+
+
+class SnerfLossGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in LOSS_GRAD_FIELDS]
+
+
+class SnerfProfile(C.Structure):
+    _fields_ = [("ms", C.c_double * 4), ("flops", C.c_double * 4), ("launches", C.c_int64 * 4)]
+
+
+PROFILE_VARIANTS = ("gemm_kernel<128,128,64,64,false,false> fwd X.W^T", "gemm_kernel<128,128,64,64,false,true> dX=dZ.W",
+                    "gemm_kernel<128,128,64,64,true,true> dW=dZ^T.X", "gemm_kernel 32-wide head variants")
+
 _lib = None
 
 
@@ -85,6 +115,17 @@ def lib():
     L.snerf_test_gemm.restype = C.c_int
     L.snerf_test_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.snerf_loss_workspace_bytes.restype = C.c_size_t
+    L.snerf_loss_workspace_bytes.argtypes = [C.POINTER(SnerfLossCfg)]
+    L.snerf_loss_partial.restype = C.c_int
+    L.snerf_loss_partial.argtypes = [C.POINTER(SnerfLossCfg), C.POINTER(SnerfLossIn), C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.c_void_p]
+    L.snerf_loss_finish.restype = C.c_int
+    L.snerf_loss_finish.argtypes = [C.POINTER(SnerfLossCfg), C.POINTER(SnerfLossIn), C.c_void_p, C.c_float, C.c_float,
+                                    C.c_void_p, C.POINTER(SnerfLossGrads), C.c_void_p]
+    L.snerf_profile_begin.restype = C.c_int
+    L.snerf_profile_end.restype = C.c_int
+    L.snerf_profile_end.argtypes = [C.POINTER(SnerfProfile)]
     if L.snerf_version() != 1:
         raise RuntimeError(f"libsnerf_hip.so ABI version {L.snerf_version()} != 1")
     _lib = L
@@ -97,4 +138,6 @@ def check(rc, what):
 
 
 EXPORTED_SYMBOLS = ("snerf_version", "snerf_last_error", "snerf_packed_floats", "snerf_workspace_bytes",
-                    "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward", "snerf_test_gemm")
+                    "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward", "snerf_test_gemm",
+                    "snerf_loss_workspace_bytes", "snerf_loss_partial", "snerf_loss_finish", "snerf_profile_begin",
+                    "snerf_profile_end")

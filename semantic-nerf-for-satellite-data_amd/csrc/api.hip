@@ -518,6 +518,9 @@ int snerf_backward(const SnerfDesc* desc, const float* packed_params, const Sner
   return backward_impl(p, packed_params, in, gout, packed_grads, d_t, d_t_s, ws, (hipStream_t)stream);
 }
 
+int snerf_profile_begin(void) { return profile_begin(); }
+int snerf_profile_end(SnerfProfile* out) { return profile_end(out); }
+
 int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, int b_ic, float* C, int ldc, int I,
                     int J, int K, int narrow, void* stream) {
   GemmArgs g;

@@ -19,25 +19,34 @@ __device__ __forceinline__ float softplus_grad_f(float x) { return x > 20.f ? 1.
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
 // Accurate sincos for SIREN / positional encoding arguments.
-// Cody-Waite reduction by pi/2 split in four parts (exact products for |k| < 2^15), then
-// minimax polynomials on [-pi/4, pi/4].  |x| <= ~3e4 stays below 2 ulp; larger arguments fall back to
-// the device library's Payne-Hanek path.  (The reference evaluates torch.sin on the ATen CPU/GPU
-// kernels, i.e. <= 1-2 ulp; hardware v_sin_f32 is NOT accurate enough once amplified by w0=30.)
+// Cody-Waite reduction by pi/2 split in four parts (exact products for |k| < 2^15), then Chebyshev-fit
+// polynomials on [-pi/4, pi/4]: <= 1.55 ulp / 9.3e-8 abs for |x| <= 3e4 (measured against fp64).
+// Larger arguments take a double-precision three-part reduction (valid to |x| ~ 1.6e6; beyond that the
+// spacing of fp32 itself exceeds 0.1 rad).  No library call: ocml's sincosf keeps Payne-Hanek tables in
+// scratch, which would push the GEMM accumulators out of registers.  (The reference evaluates torch.sin
+// on ATen kernels, <= 1-2 ulp; hardware v_sin_f32 is NOT accurate enough once amplified by w0 = 30.)
 __device__ __forceinline__ void sincos_acc(float x, float* s, float* c) {
-  if (__builtin_expect(fabsf(x) > 30000.f, 0)) {
-    sincosf(x, s, c);
-    return;
+  float r;
+  int k;
+  if (__builtin_expect(fabsf(x) <= 30000.f, 1)) {
+    const float kf = rintf(x * 0.63661977236758134308f);  // x * 2/pi
+    k = (int)kf;
+    // pi/2 = A + B + C + D; A and B carry few mantissa bits so kf*A, kf*B are exact for |kf| < 2^15
+    r = fmaf(kf, -1.5703125f, x);
+    r = fmaf(kf, -4.837512969970703125e-4f, r);
+    r = fmaf(kf, -7.549790126404332e-08f, r);
+    r = fmaf(kf, 1.7151245100058819e-15f, r);
+  } else {
+    const double xd = (double)x;
+    const double kd = rint(xd * 0.63661977236758134308);
+    double rd = fma(kd, -1.57079632673412561417e+00, xd);  // 33-bit pieces of pi/2 (fdlibm pio2_1..3)
+    rd = fma(kd, -6.07710050630396597660e-11, rd);
+    rd = fma(kd, -2.02226624871116645580e-21, rd);
+    r = (float)rd;
+    k = (int)((long long)kd & 3);
   }
-  const float kf = rintf(x * 0.63661977236758134308f);  // x * 2/pi
-  const int k = (int)kf;
-  // pi/2 = A + B + C + D; A and B carry few mantissa bits so kf*A, kf*B are exact for |kf| < 2^15
-  float r = fmaf(kf, -1.5703125f, x);
-  r = fmaf(kf, -4.837512969970703125e-4f, r);
-  r = fmaf(kf, -7.549790126404332e-08f, r);
-  r = fmaf(kf, 1.7151245100058819e-15f, r);
   const float r2 = r * r;
-  // sin(r) = r + r^3 P(r^2), cos(r) = 1 - r^2/2 + r^4 Q(r^2) on |r| <= pi/4 (Chebyshev fits,
-  // fit error 2e-11 / 1e-12; measured on CPU in fp32: <= 1.55 ulp, 9.3e-8 abs for |x| <= 3e4)
+  // sin(r) = r + r^3 P(r^2), cos(r) = 1 - r^2/2 + r^4 Q(r^2)
   float ps = fmaf(r2, 2.7237618203173253e-06f, -0.00019839989971755576f);
   ps = fmaf(ps, r2, 0.00833333169215251f);
   ps = fmaf(ps, r2, -0.16666666663377128f);

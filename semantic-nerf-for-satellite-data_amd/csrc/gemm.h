@@ -2,6 +2,7 @@
 // of the MLP (forward, dX and dW).  See gemm.hip for the kernel; DESIGN.md "Kernels" for the roofline.
 #pragma once
 #include "common.h"
+#include "../../include/snerf_hip.h"
 
 namespace snerf {
 
@@ -35,5 +36,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
+int profile_begin();
+int profile_end(struct ::SnerfProfile* out);
 
 }  // namespace snerf

@@ -18,6 +18,8 @@
 #include "gemm.h"
 #include "../../include/snerf_hip.h"
 
+#include <vector>
+
 namespace snerf {
 
 constexpr int BK = 32;
@@ -143,12 +145,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const KArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
 
-  // which 32x32 MFMA tiles of this wave are inside the problem (wave-uniform)
-  bool live_i[MI], live_j[NJ];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) live_i[mi] = (i0 + wi0 + 32 * mi) < p.I;
-#pragma unroll
-  for (int nj = 0; nj < NJ; ++nj) live_j[nj] = (j0 + wj0 + 32 * nj) < p.J;
+  // a wave whose whole WI x WJ tile lies outside the problem skips its MFMAs (wave-uniform);
+  // partially covered tiles compute on zero-filled LDS rows and mask the stores instead.
+  const bool wave_live = (i0 + wi0 < p.I) && (j0 + wj0 < p.J);
 
   float4 ra[TA::NV], rb[TB::NV];
   if (nkt > 0) {
@@ -170,19 +169,20 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const KArgs p) {
     }
     const float* la = sa + (lane >> 5) * TA::PITCH + wi0 + (lane & 31);
     const float* lb = sb + (lane >> 5) * TB::PITCH + wj0 + (lane & 31);
+    if (wave_live) {
 #pragma unroll
-    for (int kp = 0; kp < BK / 2; ++kp) {
-      float a[MI], b[NJ];
+      for (int kp = 0; kp < BK / 2; ++kp) {
+        float a[MI], b[NJ];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) a[mi] = la[(2 * kp) * TA::PITCH + 32 * mi];
+        for (int mi = 0; mi < MI; ++mi) a[mi] = la[(2 * kp) * TA::PITCH + 32 * mi];
 #pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) b[nj] = lb[(2 * kp) * TB::PITCH + 32 * nj];
+        for (int nj = 0; nj < NJ; ++nj) b[nj] = lb[(2 * kp) * TB::PITCH + 32 * nj];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int nj = 0; nj < NJ; ++nj)
-          if (live_i[mi] && live_j[nj])
+          for (int nj = 0; nj < NJ; ++nj)
             acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+      }
     }
     if (more) {
       float* da = lds + ((kt + 1) & 1) * STAGE;
@@ -193,27 +193,28 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const KArgs p) {
   }
 
   // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  if (!wave_live) return;
   const int lc = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int nj = 0; nj < NJ; ++nj) {
-    if (!live_j[nj]) continue;
     const int col = j0 + wj0 + 32 * nj + lc;
     const bool col_ok = col < p.J;
     const float bj = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-      if (!live_i[mi]) continue;
+      const int row0 = i0 + wi0 + 32 * mi + 4 * lh;
       float cs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = i0 + wi0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int row = row0 + (r & 3) + 8 * (r >> 2);
         const bool ok = col_ok && row < p.I;
+        const size_t off = (size_t)row * p.ldc + col;
         float v = acc[mi][nj][r] + bj;
         if (p.act == ACT_SIN) {
-          float s, c;
-          sincos_acc(p.w0 * v, &s, &c);
-          v = s;
-          if (p.C2 != nullptr && ok) p.C2[(size_t)row * p.ldc + col] = p.w0 * c;
+          float sn, cn;
+          sincos_acc(p.w0 * v, &sn, &cn);
+          v = sn;
+          if (p.C2 != nullptr && ok) p.C2[off] = p.w0 * cn;
         } else if (p.act == ACT_RELU) {
           v = fmaxf(v, 0.f);
         }
@@ -221,21 +222,44 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const KArgs p) {
           const float x = ok ? p.aux[(size_t)row * p.ldaux + col] : 0.f;
           v = (p.aux_mode == AUX_MUL) ? v * x : (x > 0.f ? v : 0.f);
         }
-        if (ok) C[(size_t)row * p.ldc + col] = v;
+        if (ok) C[off] = v;
         cs += ok ? v : 0.f;
       }
       if (p.colsum != nullptr) {
         cs += __shfl_xor(cs, 32, 64);
-        // this wave-tile covers rows [i0 + wi0 + 32 mi, +32): one partial per 32-row block
+        // one partial per 32-row block: this MFMA tile covers rows [i0 + wi0 + 32 mi, +32)
         const int rb32 = (i0 + wi0 + 32 * mi) >> 5;
-        if (lh == 0 && col_ok) p.colsum[(size_t)rb32 * p.ldcs + col] = cs;
+        if (lh == 0 && col_ok && (i0 + wi0 + 32 * mi) < p.I) p.colsum[(size_t)rb32 * p.ldcs + col] = cs;
       }
     }
   }
 }
 
+// ---- optional per-launch timing (snerf_profile_begin/_end): HIP events on the launch stream ----------
+struct ProfRec { hipEvent_t a, b; double flops; int variant; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_prof_pool;
+static size_t g_prof_used = 0;
+
+static hipEvent_t prof_event() {
+  if (g_prof_used == g_prof_pool.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    g_prof_pool.push_back(e);
+  }
+  return g_prof_pool[g_prof_used++];
+}
+
 template <int BI, int BJ, int WI, int WJ, bool A_IC, bool B_IC>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
+  ProfRec rec{nullptr, nullptr, 0.0, 3};
+  if (g_prof_on) {
+    rec.a = prof_event(); rec.b = prof_event();
+    rec.flops = 2.0 * (double)g.I * (double)g.J * (double)g.K;
+    if (BI == 128 && BJ == 128) rec.variant = A_IC ? 2 : (B_IC ? 1 : 0);
+    if (rec.a && rec.b) (void)hipEventRecord(rec.a, stream);
+  }
   KArgs p;
   p.A = g.A; p.A2 = g.A2 ? g.A2 : g.A; p.B = g.B; p.C = g.C; p.C2 = g.C2;
   p.bias = g.bias; p.aux = g.aux; p.colsum = g.colsum;
@@ -248,6 +272,34 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
   dim3 grid(p.tiles_i * p.tiles_j, 1, g.k_split > 0 ? g.n_split : 1);
   hipLaunchKernelGGL((gemm_kernel<BI, BJ, WI, WJ, A_IC, B_IC>), grid, dim3(NT), 0, stream, p);
   SNERF_LAUNCH_CHECK();
+  if (g_prof_on && rec.a && rec.b) {
+    (void)hipEventRecord(rec.b, stream);
+    g_prof.push_back(rec);
+  }
+  return SNERF_OK;
+}
+
+int profile_begin() {
+  g_prof.clear();
+  g_prof_used = 0;
+  g_prof_on = true;
+  return SNERF_OK;
+}
+
+int profile_end(SnerfProfile* out) {
+  g_prof_on = false;
+  if (!out) { set_error("snerf_profile_end: null output"); return SNERF_ERR_NULL; }
+  for (int v = 0; v < SNERF_PROFILE_VARIANTS; ++v) { out->ms[v] = 0.0; out->flops[v] = 0.0; out->launches[v] = 0; }
+  for (const ProfRec& r : g_prof) {
+    SNERF_HIP_CHECK(hipEventSynchronize(r.b));
+    float ms = 0.f;
+    SNERF_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+    out->ms[r.variant] += ms;
+    out->flops[r.variant] += r.flops;
+    out->launches[r.variant] += 1;
+  }
+  g_prof.clear();
+  g_prof_used = 0;
   return SNERF_OK;
 }
 

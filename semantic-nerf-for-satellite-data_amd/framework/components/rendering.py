@@ -1,0 +1,45 @@
+"""Renderer base -- mirror of framework/components/rendering.py:119-174 (BaseRenderer).
+
+Stratified sampling (reference sample_rays, :84-116) is fused into the HIP pass: render_rays only
+draws the jitter tensor (the reference calls torch.rand_like with perturb=1.0 on every call, train
+and eval alike) and hands it down; z_vals / xyz never materialise on the host side."""
+import abc
+import functools
+
+import torch
+
+from .rays import ray_component_fn
+
+
+@functools.lru_cache(maxsize=16)
+def _host_linspace(n: int):
+    # computed on the host like the CPU reference does (torch.linspace(0, 1, S)); GPU linspace may
+    # differ in the last bit, which would break bit-exact z_vals.
+    return torch.linspace(0, 1, n)
+
+
+def z_steps_on(device, n: int) -> torch.Tensor:
+    return _host_linspace(n).to(device)
+
+
+class BaseRenderer:
+    def __init__(self, cfgs) -> None:
+        super().__init__()
+        self.cfgs = cfgs
+        self.N_samples = cfgs.pipeline.n_samples
+
+    def render_rays(self, models: dict, rays: torch.Tensor, extras: torch.Tensor, epoch=None, progress=1.0,
+                    render_options={}):
+        rays_d = ray_component_fn(rays, "directions")
+        opts = dict(render_options) if render_options else {}
+        if "perturb_rand" not in opts and opts.get("perturb", 1.0) > 0:
+            opts["perturb_rand"] = torch.rand(rays.shape[0], self.N_samples, device=rays.device, dtype=torch.float32)
+        model_results = self._model_rendering(models, "coarse", self.cfgs, rays, extras, None, None, rays_d,
+                                              epoch=epoch, progress=progress, render_options=opts)
+        # "_coarse" postfix as in the reference (no fine network is ever built)
+        return {f"{k}_coarse": v for k, v in model_results.items()}
+
+    @abc.abstractmethod
+    def _model_rendering(self, models: dict, typ: str, cfgs, rays, extras, xyz, z_vals, rays_d, epoch=None,
+                         progress=1.0, render_options=None) -> dict:
+        pass

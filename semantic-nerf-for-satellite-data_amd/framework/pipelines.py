@@ -1,0 +1,151 @@
+"""Pipeline base, plugin loader and training loop -- mirror of framework/pipelines.py:22-352.
+
+Lightning is not part of this build: `Pipeline` is a plain nn.Module exposing the hooks the reference's
+LightningModule subclass defines (_init_datasets/_init_loss/_init_models/_init_renderer/_init_visualizers/
+_init_training_step, models registered as attributes model_<key> so state_dict keys keep the
+`model_<key>.` prefix that load_ckpoint.py:94-129 filters on), and `run_pipeline` is a small
+single-process-per-GPU loop (Adam + StepLR per epoch, gradient all-reduce under torch.distributed)."""
+import abc
+import importlib
+import time
+
+import torch
+
+from .. import parallel
+
+
+class Pipeline(torch.nn.Module):
+    def __init__(self, cfgs, ckpt_info=None) -> None:
+        super().__init__()
+        self.optimizer = None
+        self.cfgs = cfgs
+        self.train_steps = 0
+        self.current_epoch = 0
+        self.epoch_from_ckpt = None
+        if ckpt_info is not None:
+            self.epoch_from_ckpt, self.train_steps = ckpt_info
+        self.logged = {}
+        self.log_metrics = True
+        self.datasets = self._init_datasets()
+        assert "rgb" in self.datasets and "rgb_test" in self.datasets, "need both rgb and rgb_test datasets in pipeline"
+        self.models = self.__init_models()
+        self.renderer = self._init_renderer()
+        self.visualizers = self._init_visualizers()
+        self._training_step = self._init_training_step()
+        self._time_of_last_step = None
+        self._init_loss()
+
+    # ---- Lightning-compatible helpers -------------------------------------------------------------
+    def log(self, name, value, **kwargs):
+        self.logged[name] = value
+
+    def get_current_epoch(self):
+        if self.epoch_from_ckpt is not None:
+            return self.epoch_from_ckpt
+        return self.current_epoch
+
+    def get_current_progress(self, tstep=None):
+        if tstep is None:
+            tstep = self.train_steps
+        return tstep / self.cfgs.run.max_train_steps
+
+    def load_datasets(self):
+        dev = next(self.parameters()).device
+        for ds in self.datasets.values():
+            ds.to(dev)
+
+    def configure_optimizers(self):
+        assert False, "needs to be implemented by subclass"
+
+    def forward(self, data: dict):
+        assert False, "needs to be implemented by sub class"
+
+    def training_step(self, batch, batch_idx):
+        assert False, "needs to be implemented by sub class"
+
+    # ---- hooks ------------------------------------------------------------------------------------
+    @abc.abstractmethod
+    def _init_datasets(self) -> dict:
+        pass
+
+    @abc.abstractmethod
+    def _init_loss(self):
+        pass
+
+    def __init_models(self) -> dict:
+        models = self._init_models()
+        for key in models.keys():
+            setattr(self, f"model_{key}", models[key])
+            models[key] = getattr(self, f"model_{key}")
+        return models
+
+    @abc.abstractmethod
+    def _init_models(self) -> dict:
+        pass
+
+    @abc.abstractmethod
+    def _init_renderer(self):
+        pass
+
+    def _init_visualizers(self) -> list:
+        return []  # visualisers are out of scope
+
+    @abc.abstractmethod
+    def _init_training_step(self):
+        pass
+
+
+def load_pipeline(cfgs, ckpt_info=None) -> Pipeline:
+    """Instantiate the class named by `pipeline = "pkg.mod.Class"` (framework/pipelines.py:341-352)."""
+    name = cfgs.pipeline.pipeline.split(".")
+    module = importlib.import_module(".".join(name[:-1]))
+    return getattr(module, name[-1])(cfgs, ckpt_info=ckpt_info)
+
+
+class TrainLoop:
+    """One optimiser step = sample batch (GPU ray bank) -> training_step (main + sc forward, losses) ->
+    backward -> one flat gradient all-reduce (RCCL) -> Adam; StepLR(0.9) at epoch boundaries
+    (base_ray_pipeline.py:246-269, framework/util/train_util.py:45-60)."""
+
+    def __init__(self, pipeline, cfgs, device=None):
+        self.rank, self.world = parallel.world()
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.pipeline, self.cfgs, self.device = pipeline, cfgs, device
+        pipeline.to(device)
+        pipeline.load_datasets()
+        opt = pipeline.configure_optimizers()
+        self.optimizer, self.scheduler = opt["optimizer"], opt["lr_scheduler"]["scheduler"]
+        self.global_batch = cfgs.pipeline.batch_size
+        self.bank = pipeline.datasets["rgb"]
+        self.steps_per_epoch = self.bank.steps_per_epoch(self.global_batch)
+        self.params = [p for p in pipeline.parameters() if p.requires_grad]
+        self.bucket = None
+        self.shuffle = bool(cfgs.run.shuffle_dataset)
+
+    def step(self, step: int):
+        pl = self.pipeline
+        pl.current_epoch = step // self.steps_per_epoch
+        batch = {"rgb": self.bank.batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)}
+        if "depth" in pl.datasets:
+            batch["depth"] = pl.datasets["depth"].batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)
+        self.optimizer.zero_grad(set_to_none=True)
+        out = pl.training_step(batch, step)
+        out["loss"].backward()
+        self.bucket = parallel.allreduce_gradients(self.params, self.bucket)
+        self.optimizer.step()
+        if (step + 1) % self.steps_per_epoch == 0:
+            self.scheduler.step()
+        return out
+
+
+def run_pipeline(pipeline, cfgs, device=None, max_steps=None, on_step=None):
+    """Training loop (replaces pl.Trainer.fit of framework/pipelines.py:238-331)."""
+    loop = TrainLoop(pipeline, cfgs, device)
+    steps = max_steps if max_steps is not None else cfgs.run.max_train_steps
+    t0 = time.time()
+    for step in range(pipeline.train_steps, steps):
+        out = loop.step(step)
+        if on_step is not None:
+            on_step(step, out)
+    return time.time() - t0

@@ -1,0 +1,142 @@
+"""Fused HIP losses (snerf_loss_partial / snerf_loss_finish) as one autograd.Function.
+
+The Function returns (total, terms): `total` is the differentiable sum of the active terms, `terms`
+the eight loss_dict values (include/snerf_hip.h SNERF_TERM_*) for logging.  The gradients w.r.t. the
+rendered tensors are produced by the same kernels in the forward call and scaled in backward.
+Under data parallelism the per-ray sums/counts are all-reduced between the two phases so that means
+with data-dependent denominators (CE over non-ignored rays, L_t over car rays) equal the single-GPU
+result.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from .ops import _ptr, _stream, _check_dev
+
+
+@dataclass(frozen=True)
+class LossSpec:
+    color_mode: int = 0        # 0 none, 1 SNerfLoss, 2 SatNerfLoss
+    has_sc: bool = False
+    sem_mode: int = 0          # 0 none, 1 SemanticLoss, 2 SemanticUncertaintyLoss
+    ignore_index: int = -100
+    use_sbeta: bool = False
+    detach_beta_for_s: bool = False
+    car_reg: bool = False
+    car_label: int = 4
+    has_depth: bool = False
+    sc_lambda: float = 0.0
+    lambda_s: float = 0.0
+    lambda_c: float = 0.0
+    ds_lambda: float = 0.0
+    n_classes: int = 0
+
+
+_DIFF = ("rgb", "weights", "beta", "beta_semantic", "semantic_logits", "sun_sc", "depth")
+
+
+def _dist_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+class _FusedLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, spec: LossSpec, aux: dict, sync: bool, *diff):
+        L = _lib.lib()
+        t = dict(zip(_DIFF, diff))
+        ref = next(v for v in diff if v is not None)
+        dev = ref.device
+        N = ref.shape[0]
+        S = 1
+        for k in ("weights", "sun_sc"):
+            if t[k] is not None:
+                S = t[k].shape[1]
+        cfg = _lib.SnerfLossCfg(
+            n_rays=N, n_samples=S, n_classes=spec.n_classes, color_mode=spec.color_mode, has_sc=int(spec.has_sc),
+            sem_mode=spec.sem_mode, ignore_index=spec.ignore_index, use_sbeta=int(spec.use_sbeta),
+            detach_beta_for_s=int(spec.detach_beta_for_s), car_reg=int(spec.car_reg), car_label=spec.car_label,
+            has_depth=int(spec.has_depth), sc_lambda=spec.sc_lambda, lambda_s=spec.lambda_s, lambda_c=spec.lambda_c,
+            ds_lambda=spec.ds_lambda)
+        li = _lib.SnerfLossIn()
+        keep = []
+        for k in _DIFF:
+            if t[k] is not None:
+                _check_dev(t[k], k)
+                v = t[k].detach().contiguous()
+                keep.append(v)
+                setattr(li, k, v.data_ptr())
+        for k in ("transparency_sc", "weights_sc", "gt_rgb", "gt_depth", "depth_weights"):
+            v = aux.get(k)
+            if v is not None:
+                v = v.detach().to(torch.float32).contiguous()
+                if not v.is_cuda:
+                    raise RuntimeError(f"snerf_amd: loss input '{k}' must live on the GPU")
+                keep.append(v)
+                setattr(li, k, v.data_ptr())
+        if aux.get("labels") is not None:
+            v = aux["labels"].reshape(-1).to(torch.int64).contiguous()
+            keep.append(v)
+            li.labels = v.data_ptr()
+        if aux.get("mask") is not None:
+            v = aux["mask"].reshape(-1).to(torch.uint8).contiguous()
+            keep.append(v)
+            li.mask = v.data_ptr()
+        nws = L.snerf_loss_workspace_bytes(C.byref(cfg))
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+        totals = torch.empty(_lib.LOSS_NTOT, dtype=torch.float32, device=dev)
+        terms = torch.empty(8, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.snerf_loss_partial(C.byref(cfg), C.byref(li), _ptr(totals), _ptr(ws), nws, _stream()),
+                       "snerf_loss_partial")
+        n_global = float(N)
+        if sync and _dist_world() > 1:
+            from .parallel import allreduce_sum_
+            allreduce_sum_(totals)           # sums and counts over all ranks (tiny: 16 floats)
+            n_global = float(N) * _dist_world()  # equal shards per rank (the sampler guarantees it)
+        grads = {k: (torch.empty_like(t[k], memory_format=torch.contiguous_format) if t[k] is not None else None)
+                 for k in _DIFF}
+        lg = _lib.SnerfLossGrads()
+        for k in _DIFF:
+            if grads[k] is not None:
+                setattr(lg, k, grads[k].data_ptr())
+        with torch.cuda.device(dev):
+            _lib.check(L.snerf_loss_finish(C.byref(cfg), C.byref(li), _ptr(totals), n_global, 1.0, _ptr(terms),
+                                           C.byref(lg), _stream()), "snerf_loss_finish")
+        ctx.grads = [grads[k] for k in _DIFF]
+        ctx._keep = keep
+        total = terms.sum()
+        ctx.mark_non_differentiable(terms)
+        return total, terms
+
+    @staticmethod
+    def backward(ctx, g_total, _g_terms):
+        out = [None, None, None]
+        for g in ctx.grads:
+            out.append(None if g is None else g * g_total)
+        return tuple(out)
+
+
+def fused_loss(spec: LossSpec, results: dict, aux: dict, typ: str = "coarse", sync: bool = True):
+    """results: the renderer's dict (keys with `_coarse` suffix); aux: targets. Returns (total, terms)."""
+    def get(k):
+        return results.get(f"{k}_{typ}")
+    need_wb = spec.color_mode == 2 or spec.sem_mode == 2 or spec.car_reg
+    diff = [get("rgb") if spec.color_mode else None,
+            get("weights") if need_wb else None,
+            get("beta") if need_wb else None,
+            get("beta_semantic") if (spec.use_sbeta and spec.sem_mode == 2) else None,
+            get("semantic_logits") if spec.sem_mode else None,
+            get("sun_sc") if spec.has_sc else None,
+            get("depth") if spec.has_depth else None]
+    aux = dict(aux)
+    if spec.has_sc:
+        aux["transparency_sc"] = get("transparency_sc")
+        aux["weights_sc"] = get("weights_sc")
+    return _FusedLoss.apply(spec, aux, sync, *diff)

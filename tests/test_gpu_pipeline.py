@@ -1,0 +1,279 @@
+"""GPU parity tests through the host-side mirror of the reference's operator surface
+(renderer.render_rays, loss modules, training step gating, pipeline forward, batched_inference,
+data-parallel step) -- every number is checked against the CPU oracle on the same seeded inputs."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import snerf_oracle as O
+from tests.helpers import load_fixture, fixture_params, fixture_batch, max_abs, rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT_TOL = 1e-4
+LOSS_RTOL = 2e-4
+GRAD_REL_TOL = 2e-3
+DEV = "cuda:0"
+
+
+def _pipeline_for(cfg: O.OracleCfg, batch_size, seed, max_steps=100, **extra):
+    from snerf_amd.framework.configs import MainConfig
+    from snerf_amd.framework.pipelines import load_pipeline
+    sem = cfg.model == "semantic"
+    pc = dict(pipeline=("snerf_amd.semantic.pipelines.rs_semantic.RSSemanticPipeline" if sem else
+                        "snerf_amd.baseline.pipelines.satnerf.SatNeRFPipeline"),
+              n_samples=cfg.n_samples, batch_size=batch_size, render_chunk_size=cfg.render_chunk_size,
+              fc_units=cfg.fc_units, fc_layers=cfg.fc_layers, fc_skips=list(cfg.fc_skips),
+              fc_use_full_features=cfg.fc_use_full_features, activation_function=cfg.activation_function,
+              mapping_pos_n_freq=cfg.mapping_pos_n_freq, sc_lambda=cfg.sc_lambda, first_beta_epoch=cfg.first_beta_epoch,
+              t_embedding_tau=cfg.t_embedding_tau, t_embedding_vocab=cfg.t_embedding_vocab, ds_lambda=int(cfg.ds_lambda),
+              depth_enabled=False)
+    if sem:
+        pc.update(lambda_s=cfg.lambda_s, ignore_car_index=cfg.ignore_car_index,
+                  semantic_activation_function=cfg.semantic_activation_function, use_tj_for_s=cfg.use_tj_for_s,
+                  use_beta_for_s=cfg.use_beta_for_s, use_tj_instead_of_beta=cfg.use_tj_instead_of_beta,
+                  use_separate_beta_for_s=cfg.use_separate_beta_for_s,
+                  use_separate_tj_for_semantic=cfg.use_separate_tj_for_semantic, detach_beta_for_s=cfg.detach_beta_for_s,
+                  use_car_reg_loss=cfg.use_car_reg_loss, lambda_c=cfg.lambda_c, car_reg_loss_start=cfg.car_reg_loss_start)
+    pc.update(extra)
+    cfgs = MainConfig(run={"max_train_steps": max_steps, "synthetic_rays": 2048}, pipeline=pc)
+    pipe = load_pipeline(cfgs).to(DEV)
+    params = O.init_params_numpy(cfg, seed)
+    named = dict(pipe.model_coarse.named_parameters())
+    assert list(named) == list(params)
+    with torch.no_grad():
+        for k, v in params.items():
+            named[k].copy_(torch.from_numpy(v))
+        pipe.model_t.weight.copy_(torch.from_numpy(O.init_embedding_numpy(cfg, seed)))
+        if "t_s" in pipe.models:
+            pipe.model_t_s.weight.copy_(torch.from_numpy(O.init_embedding_numpy(cfg, seed + 1)))
+    return pipe, params
+
+
+def _batch_to_dev(b):
+    return {"rgb": {"rays": b["rays"].to(DEV), "rgbs": b["rgbs"].to(DEV), "extras": b["extras"].to(DEV),
+                    "semantic": b["semantic"].to(DEV), "semantic_sparsity_mask": b["mask"].to(DEV)}}
+
+
+@pytest.mark.parametrize("name", ["sem_siren_small", "sem_relu_small", "sem_variants_small", "sem_tj_small",
+                                  "sem_cartreg_small", "satnerf_relu_small"])
+def test_training_step_matches_reference_fixture(name, monkeypatch):
+    """pipeline.training_step (renderer + fused HIP losses + gating by epoch) reproduces the reference's
+    loss_dict and parameter gradients stored in the golden fixture."""
+    z, meta, cfg = load_fixture(name)
+    b = fixture_batch(z)
+    pipe, _ = _pipeline_for(cfg, b["rays"].shape[0], meta["seed"])
+    pipe.current_epoch = meta["epoch"]
+    u = b["u"].to(DEV)
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: u.clone())  # the renderer's jitter draw
+    out = pipe.training_step(_batch_to_dev(b), 0)
+    terms = {k[len("train/"):]: float(v) for k, v in pipe.logged.items() if k.startswith("train/coarse_")}
+    ref = {k[5:]: float(z[k]) for k in z.files if k.startswith("loss_") and k != "loss_total"}
+    assert set(terms) == set(ref), (sorted(terms), sorted(ref))
+    for k, v in ref.items():
+        assert abs(terms[k] - v) <= LOSS_RTOL * max(1.0, abs(v)), (k, terms[k], v)
+    assert abs(float(out["loss"]) - float(z["loss_total"])) <= LOSS_RTOL * max(1.0, abs(float(z["loss_total"])))
+    out["loss"].backward()
+    grads = {k: p.grad for k, p in pipe.model_coarse.named_parameters()}
+    grads["model_t.weight"] = pipe.model_t.weight.grad
+    if "t_s" in pipe.models:
+        grads["model_t_s.weight"] = pipe.model_t_s.weight.grad
+    n = 0
+    for k in z.files:
+        if k.startswith("grad_"):
+            g, r = grads[k[5:]], z[k]
+            g = torch.zeros(r.shape) if g is None else g.cpu()
+            assert rel_err(g, r) <= GRAD_REL_TOL or max_abs(g, r) <= 1e-7 + 1e-3 * float(np.abs(r).max()), (k, rel_err(g, r))
+            n += 1
+    assert n >= 20
+
+
+def _rand_results(N, S, C, seed, sbeta=False):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.rand(N, S, generator=g) * 0.1
+    r = {"rgb_coarse": torch.rand(N, 3, generator=g), "weights_coarse": w,
+         "beta_coarse": torch.rand(N, S, 1, generator=g) + 0.01, "semantic_logits_coarse": torch.rand(N, C, generator=g) * 3,
+         "depth_coarse": torch.rand(N, generator=g), "sun_sc_coarse": torch.rand(N, S, 1, generator=g),
+         "transparency_sc_coarse": torch.rand(N, S, generator=g), "weights_sc_coarse": torch.rand(N, S, generator=g) * 0.1}
+    if sbeta:
+        r["beta_semantic_coarse"] = torch.rand(N, S, 1, generator=g) + 0.01
+    return r
+
+
+@pytest.mark.parametrize("S", [16, 64, 100])
+def test_loss_modules_vs_oracle(S):
+    """every loss class of the mirror (values + gradients w.r.t. every rendered tensor) vs the oracle"""
+    from snerf_amd.baseline.components.loss import SNerfLoss, SatNerfLoss, DepthLoss
+    from snerf_amd.semantic.components.loss import SemanticLoss, SemanticUncertaintyLoss, SemanticCarRegLoss
+    N, C = 77, 5
+    g = torch.Generator().manual_seed(S)
+    gt = torch.rand(N, 3, generator=g)
+    labels = torch.randint(0, C, (N, 1), generator=g)
+    mask = torch.rand(N, generator=g) > 0.3
+    dgt, dw = torch.rand(N, generator=g), torch.rand(N, generator=g)
+    cases = [
+        ("snerf", {}, lambda r: SNerfLoss(lambda_sc=0.05)(r, gt.to(DEV)), lambda r, c: O.snerf_loss(r, gt, c)),
+        ("snerf_nosc", {"sc_lambda": 0.0}, lambda r: SNerfLoss(lambda_sc=0.0)(r, gt.to(DEV)), lambda r, c: O.snerf_loss(r, gt, c)),
+        ("satnerf", {}, lambda r: SatNerfLoss(lambda_sc=0.05)(r, gt.to(DEV)), lambda r, c: O.satnerf_loss(r, gt, c)),
+        ("depth_w", {}, lambda r: DepthLoss(lambda_ds=1000)(r, dgt.to(DEV), dw.to(DEV)), lambda r, c: O.depth_loss(r, dgt, dw, c)),
+        ("depth_1", {}, lambda r: DepthLoss(lambda_ds=1000)(r, dgt.to(DEV), 1.0), lambda r, c: O.depth_loss(r, dgt, 1.0, c)),
+        ("sem_ign", {"ignore_car_index": True}, lambda r: SemanticLoss(0.04, 4, ignore_car_index=True)(r, labels.to(DEV), mask.to(DEV)),
+         lambda r, c: O.semantic_loss(r, labels, mask, c)),
+        ("sem_nomask", {"ignore_car_index": False}, lambda r: SemanticLoss(0.04, 4, ignore_car_index=False)(r, labels.to(DEV), None),
+         lambda r, c: O.semantic_loss(r, labels, None, c)),
+        ("semunc", {"ignore_car_index": True}, lambda r: SemanticUncertaintyLoss(0.04, 4, ignore_car_index=True)(r, labels.to(DEV), mask.to(DEV)),
+         lambda r, c: O.semantic_uncertainty_loss(r, labels, mask, c)),
+        ("semunc_detach", {"ignore_car_index": True, "detach_beta_for_s": True},
+         lambda r: SemanticUncertaintyLoss(0.04, 4, detach_beta_for_s=True, ignore_car_index=True)(r, labels.to(DEV), mask.to(DEV)),
+         lambda r, c: O.semantic_uncertainty_loss(r, labels, mask, c)),
+        ("semunc_sbeta", {"ignore_car_index": True, "_sbeta": True},
+         lambda r: SemanticUncertaintyLoss(0.04, 4, ignore_car_index=True)(r, labels.to(DEV), mask.to(DEV)),
+         lambda r, c: O.semantic_uncertainty_loss(r, labels, mask, c)),
+        ("car", {"lambda_c": 0.1}, lambda r: SemanticCarRegLoss(0.1, 4)(r, labels.to(DEV), mask.to(DEV)),
+         lambda r, c: O.car_reg_loss(r, labels, mask, c)),
+    ]
+    for name, cfgkw, hip_fn, ora_fn in cases:
+        sbeta = cfgkw.pop("_sbeta", False)
+        cfg = O.OracleCfg(n_samples=S, **cfgkw)
+        base = _rand_results(N, S, C, 100 + S, sbeta)
+        rh = {k: v.clone().to(DEV).requires_grad_(True) for k, v in base.items()}
+        ro = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        loss_h, ld_h = hip_fn(rh)
+        ld_o = ora_fn(ro, cfg)
+        assert set(ld_h) == set(ld_o), (name, sorted(ld_h), sorted(ld_o))
+        for k in ld_o:
+            assert abs(float(ld_h[k]) - float(ld_o[k])) <= 1e-5 * max(1.0, abs(float(ld_o[k]))), (name, k)
+        loss_h.backward()
+        O.total_loss(ld_o).backward()
+        for k in base:
+            go = ro[k].grad
+            gh = rh[k].grad
+            if go is None:
+                assert gh is None or float(gh.abs().max()) == 0.0, (name, k)
+                continue
+            assert gh is not None, (name, k)
+            assert rel_err(gh.cpu(), go) <= 2e-5 or max_abs(gh.cpu(), go) <= 1e-9, (name, k, rel_err(gh.cpu(), go))
+
+
+def test_loss_nan_semantics():
+    """empty car set -> NaN L_t; every target ignored -> NaN CE (reference behaviour, SURVEY hard parts)"""
+    from snerf_amd.semantic.components.loss import SemanticLoss, SemanticCarRegLoss
+    r = {k: v.to(DEV) for k, v in _rand_results(8, 16, 5, 1).items()}
+    labels = torch.zeros(8, 1, dtype=torch.long, device=DEV)
+    _, ld = SemanticCarRegLoss(0.1, 4)(r, labels, None)
+    assert torch.isnan(ld["coarse_car_reg_loss"])
+    _, ld = SemanticLoss(0.04, 4, ignore_car_index=True)(r, torch.full((8, 1), 4, device=DEV), None)
+    assert torch.isnan(ld["coarse_semantic"])
+
+
+def test_pipeline_forward_chunks_and_batched_inference():
+    """ray-chunk loop (render_chunk_size < N) gives the same result as one pass; batched_inference is no-grad"""
+    from snerf_amd.eval.utils.util import batched_inference
+    cfg = O.OracleCfg(fc_units=32, n_samples=16, render_chunk_size=50)
+    pipe, params = _pipeline_for(cfg, 128, 3)
+    b = O.batch_to_torch(O.synthetic_batch(128, 16, seed=9))
+    rays, extras, u = b["rays"].to(DEV), b["extras"].to(DEV), b["u"].to(DEV)
+    with torch.no_grad():
+        one = pipe.renderer.render_rays(pipe.models, rays, extras, render_options={"perturb_rand": u})
+        parts = [pipe.renderer.render_rays(pipe.models, rays[i:i + 50], extras[i:i + 50],
+                                           render_options={"perturb_rand": u[i:i + 50]}) for i in range(0, 128, 50)]
+    for k in one:
+        cat = torch.cat([p[k] for p in parts], 0)
+        assert torch.equal(one[k], cat), k
+    ora = O.render_rays(O.to_torch(params), torch.from_numpy(O.init_embedding_numpy(cfg, 3)), cfg, b["rays"], b["extras"], b["u"])
+    assert max_abs(one["rgb_coarse"].cpu(), ora["rgb_coarse"]) <= OUT_TOL
+    res = pipe({"rays": rays, "extras": extras})
+    assert res["rgb_coarse"].shape == (128, 3) and res["weights_coarse"].shape == (128, 16)
+    bi = batched_inference(pipe.cfgs, pipe.renderer, pipe.models, rays, extras)
+    assert set(bi) == set(res) and not bi["rgb_coarse"].requires_grad
+    assert bi["semantic_label_coarse"].dtype == torch.int64
+
+
+def test_inference_callable_seam():
+    """the narrowest drop-in point: inference(model, cfgs, xyz, z_vals, sun_d=, rays_t=) of the mirror module"""
+    from snerf_amd.semantic.models.rs_semantic import inference
+    z, meta, cfg = load_fixture("inference_sem_small")
+    pipe, _ = _pipeline_for(cfg, 64, meta["seed"])
+    with torch.no_grad():
+        r = inference(pipe.models["coarse"], pipe.cfgs, torch.from_numpy(z["in_xyz"]).to(DEV), torch.from_numpy(z["in_z"]).to(DEV),
+                      rays_d=None, sun_d=torch.from_numpy(z["in_sun"]).to(DEV), rays_t=torch.from_numpy(z["in_t"]).to(DEV))
+    assert set(r) == {k[4:] for k in z.files if k.startswith("out_")}
+    for k in r:
+        if k != "semantic_label":
+            assert max_abs(r[k].cpu(), z["out_" + k]) <= OUT_TOL, k
+
+
+def test_adam_trajectory_through_trainloop(monkeypatch):
+    """3 optimiser steps (Adam 5e-4) through the pipeline reproduce the reference model's loss trajectory"""
+    z, meta, cfg = load_fixture("sem_siren_small")
+    b = fixture_batch(z)
+    pipe, _ = _pipeline_for(cfg, b["rays"].shape[0], meta["seed"])
+    pipe.current_epoch = meta["epoch"]
+    u = b["u"].to(DEV)
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: u.clone())
+    opt = pipe.configure_optimizers()["optimizer"]
+    traj = []
+    for _ in range(len(z["adam_traj"])):
+        opt.zero_grad()
+        out = pipe.training_step(_batch_to_dev(b), 0)
+        traj.append(float(out["loss"]))
+        out["loss"].backward()
+        opt.step()
+    assert np.allclose(traj, z["adam_traj"], rtol=0, atol=3e-4), (traj, z["adam_traj"])
+
+
+_DDP_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from oracle import snerf_oracle as O
+from tests.test_gpu_pipeline import _pipeline_for, _batch_to_dev
+from snerf_amd import parallel
+rank, world, dev = parallel.init_distributed(backend="gloo")
+cfg = O.OracleCfg(fc_units=32, n_samples=16, use_car_reg_loss=True, car_reg_loss_start=0, first_beta_epoch=0)
+N = 96
+b = O.batch_to_torch(O.synthetic_batch(N, 16, seed=21, car_prob=0.3))
+pipe, _ = _pipeline_for(cfg, N, 5)
+lo, hi = rank * N // world, (rank + 1) * N // world
+sub = {{k: v[lo:hi] for k, v in b.items()}}
+u = sub["u"].to("cuda:0")
+torch.rand = lambda *a, **k: u.clone()
+out = pipe.training_step(_batch_to_dev(sub), 0)
+out["loss"].backward()
+params = [p for p in pipe.parameters() if p.grad is not None]
+parallel.allreduce_gradients(params)
+if rank == 0:
+    torch.save({{"loss": float(out["loss"]), "grads": {{n: p.grad.cpu() for n, p in pipe.named_parameters() if p.grad is not None}}}}, {out!r})
+dist.barrier()
+"""
+
+
+def test_data_parallel_step_equals_single_process(tmp_path, monkeypatch):
+    """2 ranks (gloo, both on this GPU) on halves of a batch == 1 process on the whole batch: count-aware loss
+    normalisation (CE over non-ignored rays, L_t over car rays) + summed gradient all-reduce."""
+    cfg = O.OracleCfg(fc_units=32, n_samples=16, use_car_reg_loss=True, car_reg_loss_start=0, first_beta_epoch=0)
+    N = 96
+    b = O.batch_to_torch(O.synthetic_batch(N, 16, seed=21, car_prob=0.3))
+    pipe, _ = _pipeline_for(cfg, N, 5)
+    u = b["u"].to(DEV)
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: u.clone())
+    out = pipe.training_step(_batch_to_dev(b), 0)
+    out["loss"].backward()
+    single = {n: p.grad.cpu() for n, p in pipe.named_parameters() if p.grad is not None}
+    monkeypatch.undo()
+    res = str(tmp_path / "ddp.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(_DDP_WORKER.format(root=ROOT, out=res))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"), cwd=ROOT)
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    ddp = torch.load(res, weights_only=True)
+    assert abs(ddp["loss"] - float(out["loss"])) <= 1e-5 * max(1.0, abs(float(out["loss"])))
+    for n, g in single.items():
+        assert rel_err(ddp["grads"][n], g) <= 1e-4 or max_abs(ddp["grads"][n], g) <= 1e-8, (n, rel_err(ddp["grads"][n], g))
