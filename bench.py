@@ -54,9 +54,10 @@ def cpu_baseline(samples, seconds_budget=25.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)  # the GPU box's CPU share for one GPU; more threads only oversubscribe the quota
     torch.set_num_threads(cores)
     cfg = O.OracleCfg(n_samples=samples)
-    n = 256
+    n = 512
     p = O.to_torch(O.init_params_numpy(cfg, 0), requires_grad=True)
     emb = torch.from_numpy(O.init_embedding_numpy(cfg, 0)).requires_grad_(True)
     b = O.batch_to_torch(O.synthetic_batch(n, samples, seed=0))

@@ -95,6 +95,10 @@ def lib():
             f"libsnerf_hip.so not found at {LIB_PATH}: the HIP extension is the product path and has no "
             "fallback. Build it with `make -C semantic-nerf-for-satellite-data_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`).")
+    # torch bundles its own HIP runtime: import it FIRST so that libsnerf_hip.so binds to the runtime that
+    # owns torch's device context and streams (loading ours first brings up a second runtime that then
+    # reports "no ROCm-capable device").
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.snerf_version.restype = C.c_int
     L.snerf_last_error.restype = C.c_char_p
