@@ -22,6 +22,22 @@ void set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------------
+// split-K choice for one dW matrix: tiles x splits ~ one full round of 256 CUs x 4 resident workgroups,
+// at least 512 contraction rows per split, at most 256 splits.  All GEMMs that fill one matrix
+// (e.g. the [gamma | h] column segments of a skip layer) share the choice made for the widest of them.
+DwSplit dw_choose(int P, int rows, int cols, bool narrow_rows) {
+  const int tiles = (narrow_rows ? 1 : (rows + 127) / 128) * ((cols + 127) / 128);
+  int ns = (1024 + tiles / 2) / tiles;
+  const int ns_max = P / 512 > 1 ? P / 512 : 1;
+  if (ns > ns_max) ns = ns_max;
+  if (ns > 256) ns = 256;
+  if (ns < 1) ns = 1;
+  DwSplit d;
+  d.k_split = round_up((P + ns - 1) / ns, 32);
+  d.ns = (P + d.k_split - 1) / d.k_split;
+  return d;
+}
+
 int make_plan(const SnerfDesc* d, Plan* pl) {
   if (!d || !pl) { set_error("null descriptor"); return SNERF_ERR_NULL; }
   Plan& p = *pl;
@@ -29,7 +45,7 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   if (d->n_rays <= 0 || d->n_samples <= 0) return bad("n_rays and n_samples must be positive");
   if ((long long)d->n_rays * d->n_samples > (1ll << 30)) return bad("n_rays * n_samples too large for one pass (chunk the rays)");
   if (d->fc_layers < 1 || d->fc_layers > SNERF_MAX_LAYERS) return bad("fc_layers out of range");
-  if (d->fc_units < 4 || (d->fc_units & 3)) return bad("fc_units must be a positive multiple of 4");
+  if (d->fc_units < 16 || (d->fc_units & 15)) return bad("fc_units must be a positive multiple of 16");
   if (d->feat_last < 4 || (d->feat_last & 3) || d->feat_last > 64 * MAX_SKY_UNITS) return bad("feat_last must be a multiple of 4, <= 512");
   if (d->n_freq < 0 || d->n_freq > 16) return bad("n_freq out of range");
   if (d->t_dim < 1 || d->t_dim > 16) return bad("t_dim out of range");
@@ -37,7 +53,7 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   if (d->skip_mask & 1u) return bad("layer 0 cannot be a skip layer");
   p.N = d->n_rays; p.S = d->n_samples; p.P = p.N * p.S; p.Pp = round_up(p.P, 128);
   p.W = d->fc_units; p.H = d->feat_last; p.L = d->fc_layers; p.F = d->n_freq;
-  p.E = p.F > 0 ? 6 * p.F : 3; p.Ep = round_up(p.E, 4);
+  p.E = p.F > 0 ? 6 * p.F : 3; p.Ep = round_up(p.E, 16);  // k-tiles (16) never straddle the [gamma | h] segments
   p.tau = d->t_dim; p.C = d->n_classes;
   p.siren = d->siren != 0; p.sem_sigmoid = d->sem_sigmoid != 0;
   p.train = (d->flags & SNERF_FLAG_TRAIN) != 0; p.sc = (d->flags & SNERF_FLAG_SC_PASS) != 0;
@@ -112,18 +128,23 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
     p.o_dsig = wtake(Pp * NARROW); p.o_dfin = wtake(Pp * NARROW); p.o_dsun = wtake(Pp * NARROW);
     p.o_colsum = wtake((size_t)p.nrb * p.maxw);
     p.o_colsum2 = wtake((size_t)64 * (p.maxw > p.sky_floats ? p.maxw : p.sky_floats));
-    // dW split-K: ~4096 contraction rows per split, at most 64 splits
-    int ns = (p.P + 4095) / 4096;
-    if (ns > 64) ns = 64;
-    if (ns < 1) ns = 1;
-    p.k_split = round_up((p.P + ns - 1) / ns, 32);
-    p.n_split = (p.P + p.k_split - 1) / p.k_split;
-    size_t biggest = (size_t)p.N1 * p.FA;
-    for (int i = 0; i < p.L; ++i) if ((size_t)p.W * p.k_tr[i] > biggest) biggest = (size_t)p.W * p.k_tr[i];
-    if ((size_t)(p.W + NARROW) * p.W > biggest) biggest = (size_t)(p.W + NARROW) * p.W;
-    if ((size_t)NARROW * p.KF > biggest) biggest = (size_t)NARROW * p.KF;
-    p.slab_floats = round_up_sz(biggest, 64);
-    p.o_slab = wtake(p.slab_floats * p.n_split);
+    // dW split-K slabs: every matrix picks its own split count (dw_choose) so that tiles x splits fills
+    // the chip; capacity = the largest (matrix floats x splits) over all matrices of this pass
+    auto need = [&](int rows, int ld, int cols, bool narrow) {
+      const DwSplit d = dw_choose(p.P, rows, cols, narrow);
+      return round_up_sz((size_t)rows * ld, 64) * d.ns;
+    };
+    size_t cap = need(p.h1w, p.FA, p.FA, false);
+    for (int i = 0; i < p.L; ++i) { const size_t c = need(p.W, p.k_tr[i], p.W, false); if (c > cap) cap = c; }
+    size_t c2 = need(p.W + NARROW, p.W, p.W, false); if (c2 > cap) cap = c2;
+    c2 = need(NARROW, p.KF, p.KF, true); if (c2 > cap) cap = c2;
+    c2 = need(NARROW, p.H, p.H, true); if (c2 > cap) cap = c2;
+    c2 = need(p.H, p.H, p.H, false); if (c2 > cap) cap = c2;
+    p.slab_floats = cap;
+    p.o_slab = wtake(p.slab_floats);
+    { size_t big = (size_t)p.N1 * p.FA; for (int i = 0; i < p.L; ++i) if ((size_t)p.W * p.k_tr[i] > big) big = (size_t)p.W * p.k_tr[i];
+      if ((size_t)(p.W + NARROW) * p.W > big) big = (size_t)(p.W + NARROW) * p.W; if ((size_t)NARROW * p.KF > big) big = (size_t)NARROW * p.KF;
+      p.o_slab2 = wtake(64 * round_up_sz(big, 64)); }
     p.o_skyslab = wtake((size_t)p.comp_blocks * 4 * p.sky_floats);
   }
   p.ws_bytes = wo;
@@ -299,17 +320,27 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
 // backward
 // ---------------------------------------------------------------------------------------------------
 // dW = dZ^T X over all points, split-K into slabs, then one deterministic reduction into g (+=).
-static int dw_gemm(const Plan& p, WS ws, const float* dz, int lddz, int I, bool narrow_i, const float* X, int ldx,
-                   int J, size_t slab_off, int ldw, hipStream_t st) {
+struct DwMat {  // one parameter matrix [rows][ldw] being accumulated in the slab area
+  DwSplit sp; size_t stride; int ldw;
+};
+static DwMat dw_begin(const Plan& p, int rows, int ldw, int cols, bool narrow_rows) {
+  DwMat m;
+  m.sp = dw_choose(p.P, rows, cols, narrow_rows);
+  m.stride = round_up_sz((size_t)rows * ldw, 64);
+  m.ldw = ldw;
+  return m;
+}
+static int dw_gemm(const Plan& p, WS ws, const DwMat& m, const float* dz, int lddz, int I, bool narrow_i, const float* X,
+                   int ldx, int J, size_t slab_off, hipStream_t st) {
   GemmArgs g;
   g.A = dz; g.lda = lddz; g.a_ic = true; g.B = X; g.ldb = ldx; g.b_ic = true;
   g.I = I; g.J = J; g.K = p.P;
-  g.C = ws.f(p.o_slab) + slab_off; g.ldc = ldw;
-  g.k_split = p.k_split; g.n_split = p.n_split; g.slab_stride = p.slab_floats; g.narrow_i = narrow_i;
+  g.C = ws.f(p.o_slab) + slab_off; g.ldc = m.ldw;
+  g.k_split = m.sp.k_split; g.n_split = m.sp.ns; g.slab_stride = m.stride; g.narrow_i = narrow_i;
   return launch_gemm(g, st);
 }
-static int dw_reduce(const Plan& p, WS ws, size_t count, float* gout, hipStream_t st) {
-  return launch_reduce_rows(ws.f(p.o_slab), p.n_split, p.slab_floats, (int)count, gout, 0, p.n_split, 1, st);
+static int dw_reduce(const Plan& p, WS ws, const DwMat& m, size_t count, float* gout, hipStream_t st) {
+  return reduce_partials(ws.f(p.o_slab), m.sp.ns, m.stride, (int)count, ws.f(p.o_slab2), gout, st);
 }
 static int bias_from_colsum(const Plan& p, WS ws, int width, float* gout, hipStream_t st) {
   return reduce_partials(ws.f(p.o_colsum), p.nrb, (size_t)p.maxw, width, ws.f(p.o_colsum2), gout, st);
@@ -347,8 +378,9 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
   const int sun_col = p.sc ? 0 : p.blk_sun * H;
   if (!p.sc) {
     // 1. final head layers
-    RC(dw_gemm(p, ws, dfin, NARROW, NARROW, true, ws.f(p.o_h1), p.h1w, p.KF, 0, p.KF, st));
-    RC(dw_reduce(p, ws, (size_t)NARROW * p.KF, gp + p.w_fin, st));
+    const DwMat mf = dw_begin(p, NARROW, p.KF, p.KF, true);
+    RC(dw_gemm(p, ws, mf, dfin, NARROW, NARROW, true, ws.f(p.o_h1), p.h1w, p.KF, 0, st));
+    RC(dw_reduce(p, ws, mf, (size_t)NARROW * p.KF, gp + p.w_fin, st));
     RC(bias_from_narrow(p, ws, dfin, gp + p.b_fin, st));
     GemmArgs g;  // dz1[:, :KF] = (dfin . W_fin) * act'
     g.A = dfin; g.lda = NARROW; g.B = pk + p.w_fin; g.ldb = p.KF; g.b_ic = true; g.I = P; g.J = p.KF; g.K = NARROW;
@@ -358,8 +390,10 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(bias_from_colsum(p, ws, p.KF, gp + p.b_h1, st));
   }
   {  // 2. sun visibility chain: output layer, layer 3, layer 2
-    RC(dw_gemm(p, ws, dsun, NARROW, NARROW, true, ws.f(p.o_s3), H, H, 0, H, st));
-    RC(dw_reduce(p, ws, (size_t)NARROW * H, gp + p.w_s4, st));
+    const DwMat m4 = dw_begin(p, NARROW, H, H, true);
+    const DwMat mh = dw_begin(p, H, H, H, false);
+    RC(dw_gemm(p, ws, m4, dsun, NARROW, NARROW, true, ws.f(p.o_s3), H, H, 0, st));
+    RC(dw_reduce(p, ws, m4, (size_t)NARROW * H, gp + p.w_s4, st));
     RC(bias_from_narrow(p, ws, dsun, gp + p.b_s4, st));
     GemmArgs g;
     g.A = dsun; g.lda = NARROW; g.B = pk + p.w_s4; g.ldb = H; g.b_ic = true; g.I = P; g.J = H; g.K = NARROW;
@@ -367,14 +401,14 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));  // dz_s3
     RC(bias_from_colsum(p, ws, H, gp + p.b_s3, st));
-    RC(dw_gemm(p, ws, ws.f(p.o_dsa), H, H, false, ws.f(p.o_s2), H, H, 0, H, st));
-    RC(dw_reduce(p, ws, (size_t)H * H, gp + p.w_s3, st));
+    RC(dw_gemm(p, ws, mh, ws.f(p.o_dsa), H, H, false, ws.f(p.o_s2), H, H, 0, st));
+    RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s3, st));
     g.A = ws.f(p.o_dsa); g.lda = H; g.B = pk + p.w_s3; g.K = H;
     g.C = ws.f(p.o_dsb); g.aux = dact(p.o_cs2, p.o_s2);
     RC(launch_gemm(g, st));  // dz_s2
     RC(bias_from_colsum(p, ws, H, gp + p.b_s2, st));
-    RC(dw_gemm(p, ws, ws.f(p.o_dsb), H, H, false, ws.f(p.o_h1) + sun_col, p.h1w, H, 0, H, st));
-    RC(dw_reduce(p, ws, (size_t)H * H, gp + p.w_s2, st));
+    RC(dw_gemm(p, ws, mh, ws.f(p.o_dsb), H, H, false, ws.f(p.o_h1) + sun_col, p.h1w, H, 0, st));
+    RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s2, st));
     g.A = ws.f(p.o_dsb); g.B = pk + p.w_s2;
     g.C = dz1 + sun_col; g.ldc = p.h1w; g.aux = dact(p.o_c1, p.o_h1) + sun_col; g.ldaux = p.h1w;
     RC(launch_gemm(g, st));  // dz1[:, sun block]
@@ -383,8 +417,9 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
   float* dfa = ws.f(p.o_dzb);  // [P][FA]
   {  // 3. fused first head layer: dW, then d[feats | extras]
     const size_t r0 = p.sc ? (size_t)p.blk_sun * H : 0;
-    RC(dw_gemm(p, ws, dz1, p.h1w, p.h1w, false, ws.f(p.o_fa), p.FA, p.FA, 0, p.FA, st));
-    RC(dw_reduce(p, ws, (size_t)p.h1w * p.FA, gp + p.w_h1 + r0 * p.FA, st));
+    const DwMat m1 = dw_begin(p, p.h1w, p.FA, p.FA, false);
+    RC(dw_gemm(p, ws, m1, dz1, p.h1w, p.h1w, false, ws.f(p.o_fa), p.FA, p.FA, 0, st));
+    RC(dw_reduce(p, ws, m1, (size_t)p.h1w * p.FA, gp + p.w_h1 + r0 * p.FA, st));
     GemmArgs g;
     g.A = dz1; g.lda = p.h1w; g.B = pk + p.w_h1 + r0 * p.FA; g.ldb = p.FA; g.b_ic = true;
     g.I = P; g.J = p.FA; g.K = p.h1w; g.C = dfa; g.ldc = p.FA;
@@ -397,9 +432,10 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
   float* dz = ws.f(p.o_dza);  // dz1 is dead from here on
   {  // 4. feats + sigma: dW for the [W + NARROW][W] matrix, then dz of the last trunk layer
     const float* hl = ws.f(p.o_h[p.L - 1]);
-    RC(dw_gemm(p, ws, dfa, p.FA, W, false, hl, W, W, 0, W, st));
-    RC(dw_gemm(p, ws, dsig, NARROW, NARROW, true, hl, W, W, (size_t)W * W, W, st));
-    RC(dw_reduce(p, ws, (size_t)(W + NARROW) * W, gp + p.w_fs, st));
+    const DwMat ms = dw_begin(p, W + NARROW, W, W, false);
+    RC(dw_gemm(p, ws, ms, dfa, p.FA, W, false, hl, W, W, 0, st));
+    RC(dw_gemm(p, ws, ms, dsig, NARROW, NARROW, true, hl, W, W, (size_t)W * W, st));
+    RC(dw_reduce(p, ws, ms, (size_t)(W + NARROW) * W, gp + p.w_fs, st));
     RC(bias_from_narrow(p, ws, dsig, gp + p.b_fs + W, st));
     GemmArgs g;
     g.A = dfa; g.lda = p.FA; g.Ka = W; g.A2 = dsig; g.lda2 = NARROW;
@@ -415,9 +451,10 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
   for (int i = p.L - 1; i >= 0; --i) {
     const bool skip = (p.skip_mask >> i) & 1u;
     const int hoff = (i > 0 && skip) ? p.Ep : 0;  // column of the h part inside W_i
-    if (i == 0 || skip) RC(dw_gemm(p, ws, dz_cur, W, W, false, ws.f(p.o_pe), p.Ep, p.Ep, 0, p.k_tr[i], st));
-    if (i > 0) RC(dw_gemm(p, ws, dz_cur, W, W, false, ws.f(p.o_h[i - 1]), W, W, hoff, p.k_tr[i], st));
-    RC(dw_reduce(p, ws, (size_t)W * p.k_tr[i], gp + p.w_tr[i], st));
+    const DwMat mt = dw_begin(p, W, p.k_tr[i], i == 0 ? p.Ep : W, false);
+    if (i == 0 || skip) RC(dw_gemm(p, ws, mt, dz_cur, W, W, false, ws.f(p.o_pe), p.Ep, p.Ep, 0, st));
+    if (i > 0) RC(dw_gemm(p, ws, mt, dz_cur, W, W, false, ws.f(p.o_h[i - 1]), W, W, hoff, st));
+    RC(dw_reduce(p, ws, mt, (size_t)W * p.k_tr[i], gp + p.w_tr[i], st));
     if (i == 0) break;
     GemmArgs g;
     g.A = dz_cur; g.lda = W; g.B = pk + p.w_tr[i] + hoff; g.ldb = p.k_tr[i]; g.b_ic = true;

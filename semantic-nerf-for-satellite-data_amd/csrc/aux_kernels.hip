@@ -84,8 +84,11 @@ __global__ void encode_kernel(EncodeArgs a) {
       pe[k * 6 + c] = s;
       pe[k * 6 + 3 + c] = co;
     }
+    if (k == 0)
+      for (int c = 6 * a.F; c < a.Ep; ++c) pe[c] = 0.f;  // pad columns are read by the GEMM (zero weights)
   } else {
-    pe[0] = x[0]; pe[1] = x[1]; pe[2] = x[2]; pe[3] = 0.f;
+    pe[0] = x[0]; pe[1] = x[1]; pe[2] = x[2];
+    for (int c = 3; c < a.Ep; ++c) pe[c] = 0.f;
   }
   if (k == 0 && a.fa != nullptr) {
     float* e = a.fa + point * a.FA + a.W;

@@ -6,15 +6,17 @@
 // 260-340; baseline/models/commons.py:27-38) forward, and their autograd backward (dX, dW, db).
 //
 // Tiling (64-wide wavefronts): 256 threads = 4 waves; block tile BI x BJ, wave tile WI x WJ made of
-// 32x32 MFMA tiles; BK = 32.  Both operands live in LDS as [k][row] (row contiguous) so that the
-// MFMA operand fetch -- lane l wants (row = l & 31, k = l >> 5) -- is a conflict-free ds_read_b32
-// for either global storage order:
+// 32x32 MFMA tiles; BK = 16; ~35 KB LDS + <= 168 VGPR -> 3 workgroups per CU.  Both operands live in LDS as
+// [k][row] (row contiguous) so that the MFMA operand fetch -- lane l wants (row = l & 31, k = l >> 5) --
+// is a conflict-free ds_read_b32 for either global storage order:
 //   KC source (k contiguous, e.g. activations X[M][K], weights W[N][K]): float4 along k from global
-//     (8 lanes cover one 128-B line), transposed on the LDS write (pitch BI+1 -> conflict-free b32 writes);
+//     (4 lanes cover one row's 64-B piece), transposed on the LDS write (pitch BI+1 -> conflict-free b32 writes);
 //   IC source (row contiguous, e.g. W read as B[k=n][j=kin] for dX, dZ/X read along m for dW):
 //     float4 along rows, ds_write_b128 as is (pitch BI+4).
-// fp32 MFMA issues at 64 cycles per 32x32x2 per SIMD, so one ds_read_b32 per MFMA keeps LDS at
-// ~1/8 of its rate; the kernel is MFMA-issue bound by construction (roofline).
+// Global loads are buffer loads (SRD in SGPRs, 32-bit per-lane offsets, hardware bounds check returns 0
+// beyond the operand) so ragged tiles need no exec-mask branches in the k-loop.
+// Epilogue: each wave transposes its 32-row accumulator blocks through a private LDS strip and then works
+// on whole rows, so bias/aux loads and the C (+cos) stores are 16-B per lane, 256 contiguous bytes per row.
 #include "gemm.h"
 #include "../../include/snerf_hip.h"
 
@@ -22,62 +24,88 @@
 
 namespace snerf {
 
-constexpr int BK = 32;
 constexpr int NT = 256;
+constexpr int BK = 16;
+constexpr unsigned OOB = 0xFFFFFFF0u;  // voffset that the buffer bounds check always rejects
 
-template <int BI, bool IC>
-struct Tile {
-  static constexpr int NV = BI / 32;                  // float4 per thread per k-tile
-  static constexpr int PITCH = IC ? BI + 4 : BI + 1;  // LDS row pitch in floats
-  static constexpr int FLOATS = BK * PITCH;
-};
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t srd_t;
 
-template <int BI, bool IC>
-__device__ __forceinline__ void g2r(float4 (&v)[BI / 32], const float* __restrict__ P, int ld,
-                                    const float* __restrict__ P2, int ld2, int Ka, int i0, int I,
-                                    int k0, int kEnd, int t) {
-#pragma unroll
-  for (int r = 0; r < BI / 32; ++r) {
-    int i, k;
-    if (IC) {
-      constexpr int V = BI / 4;
-      i = i0 + 4 * (t % V);
-      k = k0 + t / V + (NT / V) * r;
-    } else {
-      i = i0 + (t >> 3) + 32 * r;
-      k = k0 + 4 * (t & 7);
-    }
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < I && k < kEnd) {
-      const float* src;
-      if (IC) {
-        src = P + (size_t)k * ld + i;
-      } else {
-        src = (k < Ka) ? (P + (size_t)i * ld + k) : (P2 + (size_t)i * ld2 + (k - Ka));
-      }
-      x = *reinterpret_cast<const float4*>(src);
-    }
-    v[r] = x;
-  }
+__device__ __forceinline__ srd_t make_srd(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(srd_t s, unsigned off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s, off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
 template <int BI, bool IC>
-__device__ __forceinline__ void r2s(const float4 (&v)[BI / 32], float* __restrict__ lds, int t) {
+struct Tile {
+  static constexpr int PITCH = IC ? BI + 4 : BI + 1;  // LDS row pitch in floats
+  static constexpr int FLOATS = BK * PITCH;
+  static constexpr int NV = (BI * BK / 4 + NT - 1) / NT;  // float4 per thread per k-tile
+};
+
+// thread -> (row, k) of its r-th float4 in a k-tile (element e = t + NT*r of BI*BK/4).  KC: BK/4 lanes
+// cover one row's BK floats; IC: BI/4 lanes cover one k-row.
+template <int BI, bool IC>
+__device__ __forceinline__ bool tile_coord(int t, int r, int& il, int& kl) {
+  const int e = t + NT * r;
+  if (IC) {
+    constexpr int V = BI / 4;
+    il = 4 * (e % V);
+    kl = e / V;
+  } else {
+    constexpr int Q = BK / 4;
+    il = e / Q;
+    kl = 4 * (e % Q);
+  }
+  return e < BI * BK / 4;
+}
+
+// per-thread loader state of one operand: byte offsets of its float4s at k = 0 (OOB if the row is outside)
+template <int BI, bool IC>
+struct Loader {
+  static constexpr int NV = Tile<BI, IC>::NV;
+  unsigned base[NV];
+  int kl[NV];
+  __device__ __forceinline__ void init(int t, int i0, int I, int ld) {
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      int il, k;
+      const bool in = tile_coord<BI, IC>(t, r, il, k);
+      const int i = i0 + il;
+      kl[r] = k;
+      const unsigned o = IC ? ((unsigned)k * (unsigned)ld + (unsigned)i) * 4u : ((unsigned)i * (unsigned)ld + (unsigned)k) * 4u;
+      base[r] = (in && i < I) ? o : OOB;
+    }
+  }
+  // kbytes: byte offset of the tile's first k inside the segment; krem: valid k's left in the segment
+  __device__ __forceinline__ void load(float4 (&v)[NV], srd_t srd, unsigned kbytes, int krem) const {
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      const unsigned o = (base[r] != OOB && kl[r] < krem) ? base[r] + kbytes : OOB;
+      v[r] = buf_load4(srd, o);
+    }
+  }
+};
+
+template <int BI, bool IC>
+__device__ __forceinline__ void r2s(const float4 (&v)[Tile<BI, IC>::NV], float* __restrict__ lds, int t) {
   constexpr int PITCH = Tile<BI, IC>::PITCH;
 #pragma unroll
-  for (int r = 0; r < BI / 32; ++r) {
-    if (IC) {
-      constexpr int V = BI / 4;
-      const int il = 4 * (t % V);
-      const int kl = t / V + (NT / V) * r;
-      *reinterpret_cast<float4*>(&lds[kl * PITCH + il]) = v[r];
-    } else {
-      const int il = (t >> 3) + 32 * r;
-      const int kl = 4 * (t & 7);
-      lds[(kl + 0) * PITCH + il] = v[r].x;
-      lds[(kl + 1) * PITCH + il] = v[r].y;
-      lds[(kl + 2) * PITCH + il] = v[r].z;
-      lds[(kl + 3) * PITCH + il] = v[r].w;
+  for (int r = 0; r < Tile<BI, IC>::NV; ++r) {
+    int il, kl;
+    const bool in = tile_coord<BI, IC>(t, r, il, kl);
+    if (in) {
+      if (IC) {
+        *reinterpret_cast<float4*>(&lds[kl * PITCH + il]) = v[r];
+      } else {
+        lds[(kl + 0) * PITCH + il] = v[r].x;
+        lds[(kl + 1) * PITCH + il] = v[r].y;
+        lds[(kl + 2) * PITCH + il] = v[r].z;
+        lds[(kl + 3) * PITCH + il] = v[r].w;
+      }
     }
   }
 }
@@ -86,6 +114,7 @@ struct KArgs {
   const float* A; const float* A2; const float* B;
   float* C; float* C2;
   const float* bias; const float* aux; float* colsum;
+  unsigned bytesA, bytesA2, bytesB;
   int lda, lda2, Ka, ldb, I, J, K, ldc, ldaux, ldcs;
   int act, aux_mode;
   float w0;
@@ -112,18 +141,28 @@ __device__ __forceinline__ void tile_of_block(int b, int tiles_i, int tiles_j, i
 }
 
 template <int BI, int BJ, int WI, int WJ, bool A_IC, bool B_IC>
-__global__ __launch_bounds__(NT, 2) void gemm_kernel(const KArgs p) {
+__global__ __launch_bounds__(NT, 3) void gemm_kernel(const KArgs p) {
   using TA = Tile<BI, A_IC>;
   using TB = Tile<BJ, B_IC>;
   constexpr int MI = WI / 32, NJ = WJ / 32;
   constexpr int WAVES_J = BJ / WJ;
   static_assert((BI / WI) * (BJ / WJ) == 4, "4 waves per workgroup");
   constexpr int STAGE = TA::FLOATS + TB::FLOATS;
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  constexpr int EP = WJ + 4;             // pitch of the epilogue transpose strip
+  constexpr int EPI = 32 * EP;           // floats per wave
+  constexpr int LDS_FLOATS = (2 * STAGE > 4 * EPI) ? 2 * STAGE : 4 * EPI;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wi0 = (wave / WAVES_J) * WI, wj0 = (wave % WAVES_J) * WJ;
+#ifdef SNERF_ABL_CLOCK  // diagnostic build only: shader clock = d(s_memtime) / d(s_memrealtime) * 100 MHz
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // Issue arbitration on a SIMD is by priority, then age: a freshly started workgroup would otherwise crawl
+  // through its prologue behind three older MFMA-bound ones.  Non-MFMA phases (prologue, the per-tile
+  // store+fetch block, epilogue) run at raised priority; the MFMA phase at 0.
+  __builtin_amdgcn_s_setprio(2);
   int ti, tj;
   tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);
   const int i0 = ti * BI, j0 = tj * BJ;
@@ -149,90 +188,175 @@ __global__ __launch_bounds__(NT, 2) void gemm_kernel(const KArgs p) {
   // partially covered tiles compute on zero-filled LDS rows and mask the stores instead.
   const bool wave_live = (i0 + wi0 < p.I) && (j0 + wj0 < p.J);
 
+  const srd_t srdA = make_srd(p.A, p.bytesA), srdA2 = make_srd(p.A2, p.bytesA2), srdB = make_srd(p.B, p.bytesB);
+  Loader<BI, A_IC> la1, la2;
+  Loader<BJ, B_IC> lb1;
+  la1.init(t, i0, p.I, p.lda);
+  la2.init(t, i0, p.I, p.lda2);
+  lb1.init(t, j0, p.J, p.ldb);
+  const unsigned stepA = A_IC ? (unsigned)p.lda * 4u : 4u;  // bytes per unit of k
+  const unsigned stepB = B_IC ? (unsigned)p.ldb * 4u : 4u;
+
   float4 ra[TA::NV], rb[TB::NV];
+  // k-tiles never straddle the two A segments (Ka % BK == 0, checked on the host)
+  auto fetch = [&](int k0) {
+    if (k0 < p.Ka) la1.load(ra, srdA, (unsigned)k0 * stepA, min(kEnd, p.Ka) - k0);
+    else la2.load(ra, srdA2, (unsigned)(k0 - p.Ka) * 4u, kEnd - k0);
+    lb1.load(rb, srdB, (unsigned)k0 * stepB, kEnd - k0);
+  };
+  // Software pipeline (one register set, two LDS stages): at the start of iteration kt the registers hold
+  // tile kt+1 (loaded during iteration kt-1, so its vmcnt wait is free); they are written to the LDS stage that
+  // every wave finished reading before the previous barrier, and the loads of tile kt+2 are issued right away.
+  // The LDS stores then complete underneath this iteration's MFMAs instead of in front of the barrier.
   if (nkt > 0) {
-    g2r<BI, A_IC>(ra, p.A, p.lda, p.A2, p.lda2, p.Ka, i0, p.I, kBeg, kEnd, t);
-    g2r<BJ, B_IC>(rb, p.B, p.ldb, p.B, p.ldb, 0x7fffffff, j0, p.J, kBeg, kEnd, t);
+    fetch(kBeg);
     r2s<BI, A_IC>(ra, lds, t);
     r2s<BJ, B_IC>(rb, lds + TA::FLOATS, t);
+    if (nkt > 1) fetch(kBeg + BK);
   }
   __syncthreads();
+#ifdef SNERF_ABL_CLOCK
+  const unsigned long long clk_t1 = __builtin_amdgcn_s_memtime();
+#endif
 
   for (int kt = 0; kt < nkt; ++kt) {
     const float* sa = lds + (kt & 1) * STAGE;
     const float* sb = sa + TA::FLOATS;
-    const bool more = (kt + 1) < nkt;
-    if (more) {  // global loads of the next k-tile fly under this tile's MFMAs
-      const int k0 = kBeg + (kt + 1) * BK;
-      g2r<BI, A_IC>(ra, p.A, p.lda, p.A2, p.lda2, p.Ka, i0, p.I, k0, kEnd, t);
-      g2r<BJ, B_IC>(rb, p.B, p.ldb, p.B, p.ldb, 0x7fffffff, j0, p.J, k0, kEnd, t);
+#ifndef SNERF_ABL_NOGLOAD
+    if (kt + 1 < nkt) {
+      float* da = lds + ((kt + 1) & 1) * STAGE;
+      r2s<BI, A_IC>(ra, da, t);
+      r2s<BJ, B_IC>(rb, da + TA::FLOATS, t);
+      if (kt + 2 < nkt) fetch(kBeg + (kt + 2) * BK);
     }
+#endif
+    __builtin_amdgcn_s_setprio(0);
     const float* la = sa + (lane >> 5) * TA::PITCH + wi0 + (lane & 31);
     const float* lb = sb + (lane >> 5) * TB::PITCH + wj0 + (lane & 31);
     if (wave_live) {
+      // operand fragments of k-pair kp+1 are fetched from LDS while the MFMAs of k-pair kp issue
+      float a[2][MI], b[2][NJ];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) a[0][mi] = la[32 * mi];
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) b[0][nj] = lb[32 * nj];
 #pragma unroll
       for (int kp = 0; kp < BK / 2; ++kp) {
-        float a[MI], b[NJ];
+        const int cur = kp & 1, nxt = cur ^ 1;
+        if (kp + 1 < BK / 2) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[mi] = la[(2 * kp) * TA::PITCH + 32 * mi];
+          for (int mi = 0; mi < MI; ++mi) a[nxt][mi] = la[(2 * kp + 2) * TA::PITCH + 32 * mi];
 #pragma unroll
-        for (int nj = 0; nj < NJ; ++nj) b[nj] = lb[(2 * kp) * TB::PITCH + 32 * nj];
+          for (int nj = 0; nj < NJ; ++nj) b[nxt][nj] = lb[(2 * kp + 2) * TB::PITCH + 32 * nj];
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int nj = 0; nj < NJ; ++nj)
-            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[nj], acc[mi][nj], 0, 0, 0);
+            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][mi], b[cur][nj], acc[mi][nj], 0, 0, 0);
       }
     }
-    if (more) {
-      float* da = lds + ((kt + 1) & 1) * STAGE;
-      r2s<BI, A_IC>(ra, da, t);
-      r2s<BJ, B_IC>(rb, da + TA::FLOATS, t);
-    }
+    __builtin_amdgcn_s_setprio(1);
     __syncthreads();
   }
+  __builtin_amdgcn_s_setprio(2);
 
-  // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#ifdef SNERF_ABL_CLOCK
+  if (t == 0 && p.colsum != nullptr && p.aux_mode == AUX_NONE) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.colsum) + 8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.z);
+    dbg[0] = __builtin_amdgcn_s_memtime() - clk_t0;
+    dbg[1] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    dbg[2] = clk_t1 - clk_t0;
+    dbg[4] = clk_t0;
+  }
+  const unsigned long long clk_t2 = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- epilogue ----------------------------------------------------------------------------------
   if (!wave_live) return;
+#ifdef SNERF_ABL_NOEPI
+  {  // keep the accumulators live, store (almost) nothing
+    float sum = 0.f;
+    for (int mi = 0; mi < MI; ++mi) for (int nj = 0; nj < NJ; ++nj) for (int r = 0; r < 16; ++r) sum += acc[mi][nj][r];
+    if (sum == 12345.678f) C[0] = sum;
+    return;
+  }
+#endif
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).
+  // Wave-private strip [32][EP]: written in MFMA layout (conflict-free b32), read back as rows (b128).
+  float* strip = lds + wave * EPI;
+  constexpr int LPR = WJ / 4;        // lanes per row
+  constexpr int RPP = 64 / LPR;      // rows per pass
   const int lc = lane & 31, lh = lane >> 5;
+  const int rrow = lane / LPR, c4 = 4 * (lane % LPR);
+  const int col = j0 + wj0 + c4;
+  const bool col_ok = col < p.J;     // J % 4 == 0 (host check): a float4 is entirely inside or outside
+  float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias != nullptr && col_ok) bj = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll
-  for (int nj = 0; nj < NJ; ++nj) {
-    const int col = j0 + wj0 + 32 * nj + lc;
-    const bool col_ok = col < p.J;
-    const float bj = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+  for (int mi = 0; mi < MI; ++mi) {
+    const int rbase = i0 + wi0 + 32 * mi;
+    if (rbase < p.I) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int row0 = i0 + wi0 + 32 * mi + 4 * lh;
-      float cs = 0.f;
+      for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + (r & 3) + 8 * (r >> 2);
+        for (int r = 0; r < 16; ++r)
+          strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + 32 * nj + lc] = acc[mi][nj][r];
+      float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int ps = 0; ps < 32 / RPP; ++ps) {
+        const int rl = rrow + RPP * ps;
+        const int row = rbase + rl;
         const bool ok = col_ok && row < p.I;
+        float4 v = *reinterpret_cast<const float4*>(&strip[rl * EP + c4]);
+        v.x += bj.x; v.y += bj.y; v.z += bj.z; v.w += bj.w;
         const size_t off = (size_t)row * p.ldc + col;
-        float v = acc[mi][nj][r] + bj;
         if (p.act == ACT_SIN) {
-          float sn, cn;
-          sincos_acc(p.w0 * v, &sn, &cn);
-          v = sn;
-          if (p.C2 != nullptr && ok) p.C2[off] = p.w0 * cn;
+          float4 cn;
+          sincos_acc(p.w0 * v.x, &v.x, &cn.x);
+          sincos_acc(p.w0 * v.y, &v.y, &cn.y);
+          sincos_acc(p.w0 * v.z, &v.z, &cn.z);
+          sincos_acc(p.w0 * v.w, &v.w, &cn.w);
+          if (p.C2 != nullptr && ok) {
+            cn.x *= p.w0; cn.y *= p.w0; cn.z *= p.w0; cn.w *= p.w0;
+            *reinterpret_cast<float4*>(p.C2 + off) = cn;
+          }
         } else if (p.act == ACT_RELU) {
-          v = fmaxf(v, 0.f);
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
         if (p.aux_mode != AUX_NONE) {
-          const float x = ok ? p.aux[(size_t)row * p.ldaux + col] : 0.f;
-          v = (p.aux_mode == AUX_MUL) ? v * x : (x > 0.f ? v : 0.f);
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) x = *reinterpret_cast<const float4*>(p.aux + (size_t)row * p.ldaux + col);
+          if (p.aux_mode == AUX_MUL) { v.x *= x.x; v.y *= x.y; v.z *= x.z; v.w *= x.w; }
+          else { v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f; }
         }
-        if (ok) C[off] = v;
-        cs += ok ? v : 0.f;
+        if (ok) {
+          *reinterpret_cast<float4*>(C + off) = v;
+          cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+        }
       }
+#ifndef SNERF_ABL_CLOCK
       if (p.colsum != nullptr) {
-        cs += __shfl_xor(cs, 32, 64);
-        // one partial per 32-row block: this MFMA tile covers rows [i0 + wi0 + 32 mi, +32)
-        const int rb32 = (i0 + wi0 + 32 * mi) >> 5;
-        if (lh == 0 && col_ok && (i0 + wi0 + 32 * mi) < p.I) p.colsum[(size_t)rb32 * p.ldcs + col] = cs;
+        // rows of this 32-row block live on lanes with equal (lane % LPR): butterfly over the row bits
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+          cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
+          cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
+        }
+        if (lane < LPR && col_ok) *reinterpret_cast<float4*>(p.colsum + (size_t)(rbase >> 5) * p.ldcs + col) = cs;
       }
+#endif
     }
   }
+#ifdef SNERF_ABL_CLOCK
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (t == 0 && p.colsum != nullptr && p.aux_mode == AUX_NONE) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.colsum) + 8 * (size_t)(blockIdx.x + gridDim.x * blockIdx.z);
+    dbg[3] = __builtin_amdgcn_s_memtime() - clk_t2;
+    dbg[5] = clk_r0;
+    dbg[6] = __builtin_amdgcn_s_memrealtime();
+    dbg[7] = __builtin_amdgcn_s_getreg(/*HW_REG_XCC_ID*/ (20) | (0 << 6) | ((4 - 1) << 11)) + 1;
+  }
+#endif
 }
 
 // ---- optional per-launch timing (snerf_profile_begin/_end): HIP events on the launch stream ----------
@@ -265,6 +389,11 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
   p.bias = g.bias; p.aux = g.aux; p.colsum = g.colsum;
   p.lda = g.lda; p.lda2 = g.A2 ? g.lda2 : g.lda; p.Ka = g.A2 ? g.Ka : 0x7fffffff;
   p.ldb = g.ldb; p.I = g.I; p.J = g.J; p.K = g.K; p.ldc = g.ldc; p.ldaux = g.ldaux; p.ldcs = g.ldcs;
+  // operand extents for the buffer descriptors (bytes; checked < 4 GiB by launch_gemm)
+  const int K1 = g.A2 ? g.Ka : g.K;
+  p.bytesA = (unsigned)(g.a_ic ? ((size_t)(K1 - 1) * g.lda + g.I) * 4 : ((size_t)(g.I - 1) * g.lda + K1) * 4);
+  p.bytesA2 = g.A2 ? (unsigned)(((size_t)(g.I - 1) * g.lda2 + (g.K - g.Ka)) * 4) : p.bytesA;
+  p.bytesB = (unsigned)(g.b_ic ? ((size_t)(g.K - 1) * g.ldb + g.J) * 4 : ((size_t)(g.J - 1) * g.ldb + g.K) * 4);
   p.act = g.act; p.aux_mode = g.aux ? g.aux_mode : AUX_NONE; p.w0 = g.w0;
   p.k_split = g.k_split; p.slab_stride = g.slab_stride;
   p.tiles_i = (g.I + BI - 1) / BI;
@@ -313,13 +442,23 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
   };
   if (!g.A || !g.B || !g.C) return bad("null operand");
   if (g.I <= 0 || g.J <= 0 || g.K <= 0) return bad("empty problem");
-  if ((g.lda & 3) || (g.ldb & 3) || (g.A2 && (g.lda2 & 3))) return bad("leading dimensions must be multiples of 4");
-  if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || (g.A2 && ((uintptr_t)g.A2 & 15))) return bad("operands must be 16-byte aligned");
+  if ((g.lda & 3) || (g.ldb & 3) || (g.ldc & 3) || (g.A2 && (g.lda2 & 3))) return bad("leading dimensions must be multiples of 4");
+  if (((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || ((uintptr_t)g.C & 15) || (g.A2 && ((uintptr_t)g.A2 & 15)))
+    return bad("operands must be 16-byte aligned");
+  if (g.J & 3) return bad("J must be a multiple of 4 (float4 epilogue)");
+  if (g.C2 && ((uintptr_t)g.C2 & 15)) return bad("C2 must be 16-byte aligned");
+  if (g.bias && ((uintptr_t)g.bias & 15)) return bad("bias must be 16-byte aligned");
+  if (g.aux && (((uintptr_t)g.aux & 15) || (g.ldaux & 3))) return bad("aux must be 16-byte aligned with ldaux % 4 == 0");
+  if (g.colsum && (((uintptr_t)g.colsum & 15) || (g.ldcs & 3))) return bad("colsum must be 16-byte aligned with ldcs % 4 == 0");
+  const size_t lim = 0xFFFFFFF0ull / 4;  // floats addressable through a 32-bit buffer offset
+  if ((size_t)(g.a_ic ? g.K : g.I) * g.lda >= lim) return bad("A operand exceeds 4 GiB: render fewer rays per pass");
+  if (g.A2 && (size_t)g.I * g.lda2 >= lim) return bad("A2 operand exceeds 4 GiB");
+  if ((size_t)(g.b_ic ? g.K : g.J) * g.ldb >= lim) return bad("B operand exceeds 4 GiB: render fewer rays per pass");
   if (g.a_ic) { if (g.I & 3) return bad("IC A needs I % 4 == 0"); if (g.A2) return bad("two-segment A is KC only"); }
-  else { if (g.K & 3) return bad("KC A needs K % 4 == 0"); if (g.A2 && (g.Ka & 3)) return bad("Ka % 4"); }
+  else { if (g.K & 3) return bad("KC A needs K % 4 == 0"); if (g.A2 && (g.Ka % BK)) return bad("Ka must be a multiple of 16"); }
   if (g.b_ic) { if (g.J & 3) return bad("IC B needs J % 4 == 0"); }
   else { if (g.K & 3) return bad("KC B needs K % 4 == 0"); }
-  if (g.k_split > 0 && (g.k_split % BK)) return bad("k_split must be a multiple of 32");
+  if (g.k_split > 0 && (g.k_split % 32)) return bad("k_split must be a multiple of 32");
   if (g.aux && g.aux_mode != AUX_NONE && g.ldaux <= 0) return bad("aux needs ldaux");
 
   if (!g.a_ic && !g.b_ic) {

@@ -46,15 +46,17 @@ struct Plan {
   size_t o_sigo = 0, o_fino = 0, o_suno = 0;
   // backward scratch
   size_t o_dza = 0, o_dzb = 0, o_dsa = 0, o_dsb = 0, o_dsig = 0, o_dfin = 0, o_dsun = 0;
-  size_t o_colsum = 0, o_colsum2 = 0, o_slab = 0, o_skyslab = 0;
+  size_t o_colsum = 0, o_colsum2 = 0, o_slab = 0, o_slab2 = 0, o_skyslab = 0;
   int h1w = 0;       // width of the h1 buffer in this pass (N1, or H for the sc pass)
   int maxw = 0;      // widest dz buffer
-  int n_split = 1, k_split = 32;  // dW split-K
   int nrb = 0;       // 32-row blocks (colsum partials)
   int comp_blocks = 0;
   size_t slab_floats = 0;
   size_t ws_bytes = 0;
 };
+
+struct DwSplit { int ns = 1; int k_split = 32; };
+DwSplit dw_choose(int P, int rows, int cols, bool narrow_rows);
 
 // returns SNERF_OK or an error (message via set_error)
 int make_plan(const SnerfDesc* d, Plan* pl);

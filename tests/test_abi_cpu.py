@@ -51,7 +51,7 @@ def test_host_only_sizes_and_errors():
     bad = spec.desc(0, 64)
     assert L.snerf_workspace_bytes(C.byref(bad)) == 0
     assert b"n_rays" in L.snerf_last_error()
-    bad = ModelSpec(fc_units=510).desc(16, 8)
+    bad = ModelSpec(fc_units=520).desc(16, 8)
     assert L.snerf_packed_floats(C.byref(bad)) == 0
     assert b"fc_units" in L.snerf_last_error()
 
