@@ -45,6 +45,10 @@ extern "C" {
                                  trunk + sigma + sun-visibility branch and return weights/transparency/sun
                                  (semantic/components/rendering.py:59-78) */
 
+#define SNERF_FLAG_FP32_MFMA 4u /* contract on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32) instead of the default
+                                  split-bf16 form (three bf16 planes per fp32 operand, six v_mfma_f32_32x32x16_bf16
+                                  products, fp32 accumulate: same accuracy class, 2.7x less matrix-pipe time) */
+
 /* Model + batch description.  Field names follow the reference config
  * (configs/pipelines/rs_semantic.toml:13-67, semantic/pipelines/rs_semantic.py:125-141). */
 typedef struct SnerfDesc {
@@ -221,8 +225,10 @@ int snerf_loss_finish(const SnerfLossCfg* cfg, const SnerfLossIn* in, const floa
  * Between snerf_profile_begin and snerf_profile_end every GEMM launch is bracketed by HIP events on the
  * stream it is launched on; _end synchronises those events and returns, per kernel variant, the summed
  * device time, the algorithmic FLOPs (2*I*J*K of each launch) and the launch count.
- * variant 0: gemm_kernel<128,128,64,64,false,false> (forward X.W^T), 1: <..,false,true> (dX = dZ.W),
- *         2: <..,true,true> (dW = dZ^T.X, split-K), 3: the 32-wide head variants. */
+ * variant 0: 128x128 tile, both operands K-contiguous (forward X.W^T and dX = dZ.(W^T)^T),
+ *         1: 128x128 tile, mixed layouts (unused since dX reads a transposed copy of W),
+ *         2: 128x128 tile, both operands row-contiguous (dW = dZ^T.X, split-K), 3: the 32-wide head variants.
+ * Variants 0-2 run gemm_x6_kernel (split-bf16) by default, gemm_kernel (fp32 MFMA) under SNERF_FLAG_FP32_MFMA. */
 #define SNERF_PROFILE_VARIANTS 4
 typedef struct SnerfProfile {
   double ms[SNERF_PROFILE_VARIANTS];

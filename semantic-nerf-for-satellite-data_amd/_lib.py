@@ -8,6 +8,7 @@ MAX_LAYERS = 16
 
 FLAG_TRAIN = 1
 FLAG_SC_PASS = 2
+FLAG_FP32_MFMA = 4  # contract on v_mfma_f32_32x32x2_f32 instead of the default split-bf16 (x6) form
 
 _fp = C.POINTER(C.c_float)
 
@@ -79,8 +80,8 @@ class SnerfProfile(C.Structure):
     _fields_ = [("ms", C.c_double * 4), ("flops", C.c_double * 4), ("launches", C.c_int64 * 4)]
 
 
-PROFILE_VARIANTS = ("gemm_kernel<128,128,64,64,false,false> fwd X.W^T", "gemm_kernel<128,128,64,64,false,true> dX=dZ.W",
-                    "gemm_kernel<128,128,64,64,true,true> dW=dZ^T.X", "gemm_kernel 32-wide head variants")
+PROFILE_VARIANTS = ("128x128 tile, K-contiguous operands (fwd X.W^T, dX=dZ.W)", "128x128 tile, mixed layouts (unused)",
+                    "128x128 tile, row-contiguous operands (dW=dZ^T.X, split-K)", "32-wide head variants (fp32 MFMA)")
 
 _lib = None
 

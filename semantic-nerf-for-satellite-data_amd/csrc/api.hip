@@ -57,6 +57,7 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.tau = d->t_dim; p.C = d->n_classes;
   p.siren = d->siren != 0; p.sem_sigmoid = d->sem_sigmoid != 0;
   p.train = (d->flags & SNERF_FLAG_TRAIN) != 0; p.sc = (d->flags & SNERF_FLAG_SC_PASS) != 0;
+  p.x6 = (d->flags & SNERF_FLAG_FP32_MFMA) == 0;
   p.skip_mask = d->skip_mask;
   const bool sem = p.C > 0;
   const bool sbeta = sem && d->use_separate_beta_for_s;
@@ -93,6 +94,12 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.w_fin = take((size_t)NARROW * p.KF); p.b_fin = take(NARROW);
   p.sky_floats = 9 * p.H + 4;
   p.sky = take(p.sky_floats);
+  for (int i = 1; i < p.L; ++i) p.t_tr[i] = take((size_t)p.W * p.W);
+  p.t_fs = take((size_t)p.W * (p.W + NARROW));
+  p.t_h1 = take((size_t)p.FA * p.N1);
+  p.t_s2 = take((size_t)p.H * p.H); p.t_s3 = take((size_t)p.H * p.H);
+  p.t_s4 = take((size_t)p.H * NARROW);
+  p.t_fin = take((size_t)p.KF * NARROW);
   p.packed_floats = off;
 
   // ---- workspace
@@ -256,6 +263,7 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
     g.C = ws.f(p.o_h[i]); g.ldc = W;
     g.bias = pk + p.b_tr[i]; g.act = act; g.w0 = (p.siren && i == 0) ? 30.f : 1.f;
     g.C2 = (p.train && p.siren) ? ws.f(p.o_c[i]) : nullptr;
+    g.x6 = p.x6;
     RC(launch_gemm(g, st));
   }
   const float* hl = ws.f(p.o_h[p.L - 1]);
@@ -268,7 +276,7 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
   {  // feats (rs_semantic.py:338), written into the first W columns of the [feats | sun | t | t_s] buffer
     GemmArgs g;
     g.A = hl; g.lda = W; g.B = pk + p.w_fs; g.ldb = W; g.I = P; g.J = W; g.K = W;
-    g.C = ws.f(p.o_fa); g.ldc = p.FA; g.bias = pk + p.b_fs;
+    g.C = ws.f(p.o_fa); g.ldc = p.FA; g.bias = pk + p.b_fs; g.x6 = p.x6;
     RC(launch_gemm(g, st));
   }
   {  // first layer of every head in one GEMM (sc pass: sun-visibility block only)
@@ -277,14 +285,14 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
     const size_t r0 = p.sc ? (size_t)p.blk_sun * H : 0;
     g.B = pk + p.w_h1 + r0 * p.FA; g.ldb = p.FA; g.J = p.h1w;
     g.C = ws.f(p.o_h1); g.ldc = p.h1w; g.bias = pk + p.b_h1 + r0; g.act = act; g.w0 = 1.f;
-    g.C2 = (p.train && p.siren) ? ws.f(p.o_c1) : nullptr;
+    g.C2 = (p.train && p.siren) ? ws.f(p.o_c1) : nullptr; g.x6 = p.x6;
     RC(launch_gemm(g, st));
   }
   const int sun_col = p.sc ? 0 : p.blk_sun * H;
   {  // sun visibility layers 2,3 (rs_semantic.py:217-227)
     GemmArgs g;
     g.A = ws.f(p.o_h1) + sun_col; g.lda = p.h1w; g.B = pk + p.w_s2; g.ldb = H; g.I = P; g.J = H; g.K = H;
-    g.C = ws.f(p.o_s2); g.ldc = H; g.bias = pk + p.b_s2; g.act = act;
+    g.C = ws.f(p.o_s2); g.ldc = H; g.bias = pk + p.b_s2; g.act = act; g.x6 = p.x6;
     g.C2 = (p.train && p.siren) ? ws.f(p.o_cs2) : nullptr;
     RC(launch_gemm(g, st));
     g.A = ws.f(p.o_s2); g.lda = H; g.B = pk + p.w_s3; g.bias = pk + p.b_s3; g.C = ws.f(p.o_s3);
@@ -336,7 +344,7 @@ static int dw_gemm(const Plan& p, WS ws, const DwMat& m, const float* dz, int ld
   g.A = dz; g.lda = lddz; g.a_ic = true; g.B = X; g.ldb = ldx; g.b_ic = true;
   g.I = I; g.J = J; g.K = p.P;
   g.C = ws.f(p.o_slab) + slab_off; g.ldc = m.ldw;
-  g.k_split = m.sp.k_split; g.n_split = m.sp.ns; g.slab_stride = m.stride; g.narrow_i = narrow_i;
+  g.k_split = m.sp.k_split; g.n_split = m.sp.ns; g.slab_stride = m.stride; g.narrow_i = narrow_i; g.x6 = p.x6;
   return launch_gemm(g, st);
 }
 static int dw_reduce(const Plan& p, WS ws, const DwMat& m, size_t count, float* gout, hipStream_t st) {
@@ -383,7 +391,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(dw_reduce(p, ws, mf, (size_t)NARROW * p.KF, gp + p.w_fin, st));
     RC(bias_from_narrow(p, ws, dfin, gp + p.b_fin, st));
     GemmArgs g;  // dz1[:, :KF] = (dfin . W_fin) * act'
-    g.A = dfin; g.lda = NARROW; g.B = pk + p.w_fin; g.ldb = p.KF; g.b_ic = true; g.I = P; g.J = p.KF; g.K = NARROW;
+    g.A = dfin; g.lda = NARROW; g.B = pk + p.t_fin; g.ldb = NARROW; g.I = P; g.J = p.KF; g.K = NARROW; g.x6 = p.x6;
     g.C = dz1; g.ldc = p.h1w; g.aux = dact(p.o_c1, p.o_h1); g.ldaux = p.h1w; g.aux_mode = aux_mode;
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));
@@ -396,20 +404,20 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(dw_reduce(p, ws, m4, (size_t)NARROW * H, gp + p.w_s4, st));
     RC(bias_from_narrow(p, ws, dsun, gp + p.b_s4, st));
     GemmArgs g;
-    g.A = dsun; g.lda = NARROW; g.B = pk + p.w_s4; g.ldb = H; g.b_ic = true; g.I = P; g.J = H; g.K = NARROW;
+    g.A = dsun; g.lda = NARROW; g.B = pk + p.t_s4; g.ldb = NARROW; g.I = P; g.J = H; g.K = NARROW; g.x6 = p.x6;
     g.C = ws.f(p.o_dsa); g.ldc = H; g.aux = dact(p.o_cs3, p.o_s3); g.ldaux = H; g.aux_mode = aux_mode;
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));  // dz_s3
     RC(bias_from_colsum(p, ws, H, gp + p.b_s3, st));
     RC(dw_gemm(p, ws, mh, ws.f(p.o_dsa), H, H, false, ws.f(p.o_s2), H, H, 0, st));
     RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s3, st));
-    g.A = ws.f(p.o_dsa); g.lda = H; g.B = pk + p.w_s3; g.K = H;
+    g.A = ws.f(p.o_dsa); g.lda = H; g.B = pk + p.t_s3; g.ldb = H; g.K = H;
     g.C = ws.f(p.o_dsb); g.aux = dact(p.o_cs2, p.o_s2);
     RC(launch_gemm(g, st));  // dz_s2
     RC(bias_from_colsum(p, ws, H, gp + p.b_s2, st));
     RC(dw_gemm(p, ws, mh, ws.f(p.o_dsb), H, H, false, ws.f(p.o_h1) + sun_col, p.h1w, H, 0, st));
     RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s2, st));
-    g.A = ws.f(p.o_dsb); g.B = pk + p.w_s2;
+    g.A = ws.f(p.o_dsb); g.B = pk + p.t_s2;
     g.C = dz1 + sun_col; g.ldc = p.h1w; g.aux = dact(p.o_c1, p.o_h1) + sun_col; g.ldaux = p.h1w;
     RC(launch_gemm(g, st));  // dz1[:, sun block]
     RC(bias_from_colsum(p, ws, H, gp + p.b_h1 + (size_t)p.blk_sun * H, st));
@@ -421,7 +429,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(dw_gemm(p, ws, m1, dz1, p.h1w, p.h1w, false, ws.f(p.o_fa), p.FA, p.FA, 0, st));
     RC(dw_reduce(p, ws, m1, (size_t)p.h1w * p.FA, gp + p.w_h1 + r0 * p.FA, st));
     GemmArgs g;
-    g.A = dz1; g.lda = p.h1w; g.B = pk + p.w_h1 + r0 * p.FA; g.ldb = p.FA; g.b_ic = true;
+    g.A = dz1; g.lda = p.h1w; g.B = pk + p.t_h1 + r0; g.ldb = p.N1; g.x6 = p.x6;
     g.I = P; g.J = p.FA; g.K = p.h1w; g.C = dfa; g.ldc = p.FA;
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;  // columns [0,W) = bias grad of feats_from_xyz
     RC(launch_gemm(g, st));
@@ -439,7 +447,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(bias_from_narrow(p, ws, dsig, gp + p.b_fs + W, st));
     GemmArgs g;
     g.A = dfa; g.lda = p.FA; g.Ka = W; g.A2 = dsig; g.lda2 = NARROW;
-    g.B = pk + p.w_fs; g.ldb = W; g.b_ic = true; g.I = P; g.J = W; g.K = W + NARROW;
+    g.B = pk + p.t_fs; g.ldb = W + NARROW; g.I = P; g.J = W; g.K = W + NARROW; g.x6 = p.x6;
     g.C = dz; g.ldc = W; g.aux = dact(p.o_c[p.L - 1], p.o_h[p.L - 1]); g.ldaux = W; g.aux_mode = aux_mode;
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));
@@ -457,7 +465,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(dw_reduce(p, ws, mt, (size_t)W * p.k_tr[i], gp + p.w_tr[i], st));
     if (i == 0) break;
     GemmArgs g;
-    g.A = dz_cur; g.lda = W; g.B = pk + p.w_tr[i] + hoff; g.ldb = p.k_tr[i]; g.b_ic = true;
+    g.A = dz_cur; g.lda = W; g.B = pk + p.t_tr[i]; g.ldb = W; g.x6 = p.x6;
     g.I = P; g.J = W; g.K = W; g.C = dz_nxt; g.ldc = W;
     g.aux = dact(p.o_c[i - 1], p.o_h[i - 1]); g.ldaux = W; g.aux_mode = aux_mode;
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
@@ -514,6 +522,17 @@ int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* p
   hipStream_t st = (hipStream_t)stream;
   SNERF_HIP_CHECK(hipMemsetAsync(packed, 0, p.packed_floats * sizeof(float), st));
   for (int i = 0; i < tb.nt; ++i) RC(launch_copy_table(tb.tabs[i], packed, 0, st));
+  // K-contiguous transposes consumed by the dX GEMMs
+  for (int i = 1; i < p.L; ++i) {
+    const int hoff = ((p.skip_mask >> i) & 1u) ? p.Ep : 0;
+    RC(launch_transpose(packed + p.w_tr[i] + hoff, p.k_tr[i], p.W, p.W, packed + p.t_tr[i], p.W, st));
+  }
+  RC(launch_transpose(packed + p.w_fs, p.W, p.W + NARROW, p.W, packed + p.t_fs, p.W + NARROW, st));
+  RC(launch_transpose(packed + p.w_h1, p.FA, p.N1, p.FA, packed + p.t_h1, p.N1, st));
+  RC(launch_transpose(packed + p.w_s2, p.H, p.H, p.H, packed + p.t_s2, p.H, st));
+  RC(launch_transpose(packed + p.w_s3, p.H, p.H, p.H, packed + p.t_s3, p.H, st));
+  RC(launch_transpose(packed + p.w_s4, p.H, NARROW, p.H, packed + p.t_s4, NARROW, st));
+  RC(launch_transpose(packed + p.w_fin, p.KF, NARROW, p.KF, packed + p.t_fin, NARROW, st));
   return SNERF_OK;
 }
 
@@ -563,7 +582,7 @@ int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, 
   GemmArgs g;
   g.A = A; g.lda = lda; g.a_ic = a_ic != 0; g.B = B; g.ldb = ldb; g.b_ic = b_ic != 0;
   g.C = C; g.ldc = ldc; g.I = I; g.J = J; g.K = K;
-  g.narrow_j = narrow == 1; g.narrow_i = narrow == 2;
+  g.narrow_j = (narrow & 3) == 1; g.narrow_i = (narrow & 3) == 2; g.x6 = (narrow & 4) != 0;
   return launch_gemm(g, (hipStream_t)stream);
 }
 

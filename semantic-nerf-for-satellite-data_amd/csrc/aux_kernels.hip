@@ -129,6 +129,26 @@ int launch_copy_table(const CopyTable& tb, float* packed, int mode, hipStream_t 
   return 0;
 }
 
+// dst[c][r] = src[r][c] for a [rows][cols] block (32x32 tiles through LDS; both sides coalesced)
+__global__ void transpose_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, float* __restrict__ dst,
+                                 int ld_dst) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+  for (int j = ty; j < 32; j += 8)
+    if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = src[(size_t)(r0 + j) * ld_src + c0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < cols && r0 + tx < rows) dst[(size_t)(c0 + j) * ld_dst + r0 + tx] = tile[tx][j];
+}
+
+int launch_transpose(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, src, ld_src, rows, cols,
+                     dst, ld_dst);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- slab reductions ---------------------------------------------------------------------------------
 // out[g][j] (+)= sum_{q in group g} in[q][j]; deterministic (fixed order), no atomics.
 __global__ void reduce_rows_kernel(const float* __restrict__ in, int n_in, size_t in_stride, int width,

@@ -33,6 +33,7 @@ struct GemmArgs {
   int k_split = 0; int n_split = 1; size_t slab_stride = 0;
   bool narrow_j = false;  // 128x32 tile (J <= 32-wide heads)
   bool narrow_i = false;  // 32x128 tile (dW of the narrow heads)
+  bool x6 = false;        // split-bf16 MFMA (gemm_x6.hip) for the 128x128 tile when both operands share a layout
 };
 
 int launch_gemm(const GemmArgs& g, hipStream_t stream);

@@ -1,0 +1,177 @@
+// Pieces shared by the fp32-MFMA GEMM (gemm.hip) and the split-bf16 GEMM (gemm_x6.hip):
+// kernel arguments, buffer-descriptor helpers, workgroup->tile map and the fused epilogue.
+#pragma once
+#include "gemm.h"
+#include "../../include/snerf_hip.h"
+
+namespace snerf {
+
+constexpr int NT = 256;
+constexpr int BK = 16;
+constexpr unsigned OOB = 0xFFFFFFF0u;  // voffset that the buffer bounds check always rejects
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t srd_t;
+
+__device__ __forceinline__ srd_t make_srd(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(srd_t s, unsigned off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(s, off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+struct KArgs {
+  const float* A; const float* A2; const float* B;
+  float* C; float* C2;
+  const float* bias; const float* aux; float* colsum;
+  unsigned bytesA, bytesA2, bytesB;
+  int lda, lda2, Ka, ldb, I, J, K, ldc, ldaux, ldcs;
+  int act, aux_mode;
+  float w0;
+  int k_split;
+  unsigned long long slab_stride;
+  int tiles_i, tiles_j;
+};
+
+// Workgroup -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), and the J-tiles of
+// one I-tile re-read the same A rows, so give each XCD group runs of consecutive J-tiles of the
+// same I-tile: those re-reads then hit that XCD's L2 instead of HBM. Speed only, never correctness.
+__device__ __forceinline__ void tile_of_block(int b, int tiles_i, int tiles_j, int& ti, int& tj) {
+  const int n = tiles_i * tiles_j;
+  const int xcd = b & 7, q = b >> 3;
+  const int per = n >> 3;  // tiles per XCD group (exact part)
+  if (b < (per << 3)) {
+    const int lin = xcd * per + q;  // contiguous chunk of the (ti-major) tile order per XCD group
+    ti = lin / tiles_j;
+    tj = lin - ti * tiles_j;
+  } else {  // remainder tiles (n % 8): identity order
+    ti = b / tiles_j;
+    tj = b - ti * tiles_j;
+  }
+}
+
+// thread -> (row, k) of its r-th float4 in a BI x BK k-tile (element e = t + NT*r of BI*BK/4).
+// KC: BK/4 lanes cover one row's BK floats; IC: BI/4 lanes cover one k-row.
+template <int BI, bool IC>
+__device__ __forceinline__ bool tile_coord(int t, int r, int& il, int& kl) {
+  const int e = t + NT * r;
+  if (IC) {
+    constexpr int V = BI / 4;
+    il = 4 * (e % V);
+    kl = e / V;
+  } else {
+    constexpr int Q = BK / 4;
+    il = e / Q;
+    kl = 4 * (e % Q);
+  }
+  return e < BI * BK / 4;
+}
+
+// per-thread loader state of one operand: byte offsets of its float4s at k = 0 (OOB if the row is outside)
+template <int BI, bool IC>
+struct Loader {
+  static constexpr int NV = (BI * BK / 4 + NT - 1) / NT;
+  unsigned base[NV];
+  int kl[NV];
+  __device__ __forceinline__ void init(int t, int i0, int I, int ld) {
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      int il, k;
+      const bool in = tile_coord<BI, IC>(t, r, il, k);
+      const int i = i0 + il;
+      kl[r] = k;
+      const unsigned o = IC ? ((unsigned)k * (unsigned)ld + (unsigned)i) * 4u : ((unsigned)i * (unsigned)ld + (unsigned)k) * 4u;
+      base[r] = (in && i < I) ? o : OOB;
+    }
+  }
+  // kbytes: byte offset of the tile's first k inside the segment; krem: valid k's left in the segment
+  __device__ __forceinline__ void load(float4 (&v)[NV], srd_t srd, unsigned kbytes, int krem) const {
+#pragma unroll
+    for (int r = 0; r < NV; ++r) {
+      const unsigned o = (base[r] != OOB && kl[r] < krem) ? base[r] + kbytes : OOB;
+      v[r] = buf_load4(srd, o);
+    }
+  }
+};
+
+// Fused epilogue.  C/D layout of the 32x32 MFMA (fp32 and bf16 forms alike): col = lane & 31,
+// row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Each wave transposes its 32-row accumulator blocks through
+// a private LDS strip [32][WJ+4] (written in MFMA layout: conflict-free b32; read back as rows: b128) and
+// then works on whole rows: bias / aux loads and the C (+cos) stores are 16 B per lane, 256 contiguous
+// bytes per row; bias-gradient column sums by a butterfly over the row bits.
+template <int MI, int NJ, int WJ>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float* __restrict__ lds, int wave, int lane,
+                                              int row0, int col0, const KArgs& p, float* __restrict__ C) {
+  constexpr int EP = WJ + 4;
+  constexpr int EPI = 32 * EP;
+  const int i0 = row0, wi0 = 0, j0 = col0, wj0 = 0;
+  float* strip = lds + wave * EPI;
+  constexpr int LPR = WJ / 4;        // lanes per row
+  constexpr int RPP = 64 / LPR;      // rows per pass
+  const int lc = lane & 31, lh = lane >> 5;
+  const int rrow = lane / LPR, c4 = 4 * (lane % LPR);
+  const int col = j0 + wj0 + c4;
+  const bool col_ok = col < p.J;     // J % 4 == 0 (host check): a float4 is entirely inside or outside
+  float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias != nullptr && col_ok) bj = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int rbase = i0 + wi0 + 32 * mi;
+    if (rbase < p.I) {
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + 32 * nj + lc] = acc[mi][nj][r];
+      float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int ps = 0; ps < 32 / RPP; ++ps) {
+        const int rl = rrow + RPP * ps;
+        const int row = rbase + rl;
+        const bool ok = col_ok && row < p.I;
+        float4 v = *reinterpret_cast<const float4*>(&strip[rl * EP + c4]);
+        v.x += bj.x; v.y += bj.y; v.z += bj.z; v.w += bj.w;
+        const size_t off = (size_t)row * p.ldc + col;
+        if (p.act == ACT_SIN) {
+          float4 cn;
+          sincos_acc(p.w0 * v.x, &v.x, &cn.x);
+          sincos_acc(p.w0 * v.y, &v.y, &cn.y);
+          sincos_acc(p.w0 * v.z, &v.z, &cn.z);
+          sincos_acc(p.w0 * v.w, &v.w, &cn.w);
+          if (p.C2 != nullptr && ok) {
+            cn.x *= p.w0; cn.y *= p.w0; cn.z *= p.w0; cn.w *= p.w0;
+            *reinterpret_cast<float4*>(p.C2 + off) = cn;
+          }
+        } else if (p.act == ACT_RELU) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        if (p.aux_mode != AUX_NONE) {
+          float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok) x = *reinterpret_cast<const float4*>(p.aux + (size_t)row * p.ldaux + col);
+          if (p.aux_mode == AUX_MUL) { v.x *= x.x; v.y *= x.y; v.z *= x.z; v.w *= x.w; }
+          else { v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f; }
+        }
+        if (ok) {
+          *reinterpret_cast<float4*>(C + off) = v;
+          cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+        }
+      }
+#ifndef SNERF_ABL_CLOCK
+      if (p.colsum != nullptr) {
+        // rows of this 32-row block live on lanes with equal (lane % LPR): butterfly over the row bits
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+          cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
+          cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
+        }
+        if (lane < LPR && col_ok) *reinterpret_cast<float4*>(p.colsum + (size_t)(rbase >> 5) * p.ldcs + col) = cs;
+      }
+#endif
+    }
+  }
+}
+
+constexpr int epilogue_lds_floats(int WJ) { return 4 * 32 * (WJ + 4); }
+
+}  // namespace snerf

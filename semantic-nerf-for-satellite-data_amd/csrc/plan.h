@@ -37,7 +37,15 @@ struct Plan {
   size_t w_fin = 0, b_fin = 0;      // [NARROW][KF]
   size_t sky = 0;                   // [H][4] w0 | [H] b0 | [4][H] w2 | [4] b2
   int sky_floats = 0;
+  // K-contiguous transposes for the dX GEMMs (dX = dZ . W reads W^T rows): [cols of W][rows of W]
+  size_t t_tr[SNERF_MAX_LAYERS] = {0};  // h part of trunk layer i: [W][W]
+  size_t t_fs = 0;   // [W][W + NARROW]
+  size_t t_h1 = 0;   // [FA][N1]
+  size_t t_s2 = 0, t_s3 = 0;  // [H][H]
+  size_t t_s4 = 0;   // [H][NARROW]
+  size_t t_fin = 0;  // [KF][NARROW]
   size_t packed_floats = 0;
+  bool x6 = true;    // split-bf16 MFMA for the 128x128 GEMMs (fp32 MFMA when SNERF_FLAG_FP32_MFMA)
 
   // workspace layout (byte offsets)
   size_t o_z = 0, o_T = 0, o_rgbraw = 0, o_pe = 0, o_fa = 0, o_h1 = 0, o_c1 = 0;

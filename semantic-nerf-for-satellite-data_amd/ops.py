@@ -10,7 +10,12 @@ from dataclasses import dataclass, field
 
 import torch
 
+import os
+
 from . import _lib
+
+# SNERF_MFMA=fp32 forces the plain fp32 matrix instruction; default is the split-bf16 form (same accuracy class)
+BASE_FLAGS = _lib.FLAG_FP32_MFMA if os.environ.get("SNERF_MFMA", "").lower() == "fp32" else 0
 
 # parameter names in the reference's state_dict order -> SnerfParams field
 _HEAD_FIELDS = {
@@ -71,7 +76,7 @@ class ModelSpec:
             n_classes=self.n_classes, sem_sigmoid=int(self.sem_sigmoid),
             use_tj_instead_of_beta=int(self.use_tj_instead_of_beta), use_tj_for_s=int(self.use_tj_for_s),
             use_separate_beta_for_s=int(self.use_separate_beta_for_s),
-            use_separate_tj_for_semantic=int(self.use_separate_tj_for_semantic), flags=flags)
+            use_separate_tj_for_semantic=int(self.use_separate_tj_for_semantic), flags=flags | BASE_FLAGS)
 
     def param_names(self) -> list:
         names = []

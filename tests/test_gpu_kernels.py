@@ -33,6 +33,19 @@ def _dev():
     (1, 1, 0, 512, 512, 1024), (1, 1, 0, 256, 60, 777), (1, 1, 2, 32, 768, 1500), (1, 1, 0, 1024, 524, 64),
 ])
 def test_gemm_layouts(a_ic, b_ic, narrow, I, J, K):
+    _gemm_case(a_ic, b_ic, narrow, I, J, K)
+
+
+@pytest.mark.parametrize("a_ic,b_ic,I,J,K", [
+    (0, 0, 128, 128, 16), (0, 0, 256, 512, 512), (0, 0, 200, 100, 60), (0, 0, 1000, 520, 576), (0, 0, 77, 36, 1024),
+    (1, 1, 128, 128, 32), (1, 1, 512, 512, 1024), (1, 1, 256, 60, 777), (1, 1, 1024, 524, 64), (1, 1, 36, 300, 5000),
+])
+def test_gemm_split_bf16(a_ic, b_ic, I, J, K):
+    """split-bf16 (3 planes, 6 MFMA products) GEMM: exact on small integers, fp32-level error on random data"""
+    _gemm_case(a_ic, b_ic, 4, I, J, K)
+
+
+def _gemm_case(a_ic, b_ic, narrow, I, J, K):
     from snerf_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(I * 7 + J * 3 + K)

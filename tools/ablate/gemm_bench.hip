@@ -19,6 +19,7 @@ static double time_gemm(const GemmArgs& g, int reps) {
   return ms / reps;
 }
 int main(int argc, char** argv) {
+  const bool X6 = argc > 1 && argv[1][0] == 'x';
   const int P = 262144, W = 512;
   float *X, *Wt, *Y, *Y2, *dW, *cs;
   CK(hipMalloc(&X, (size_t)P * W * 4)); CK(hipMalloc(&Wt, (size_t)W * W * 4)); CK(hipMalloc(&Y, (size_t)P * W * 4));
@@ -29,7 +30,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(Y2, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(Wt, h.data(), (size_t)W * W * 4, hipMemcpyHostToDevice));
   const double fl = 2.0 * P * W * W;
-  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W;
+  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6;
     double t = time_gemm(g, 20); printf("fwd plain        %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.bias = Wt; g.act = ACT_SIN; g.w0 = 1.f;
     t = time_gemm(g, 20); printf("fwd sin          %.3f ms %.1f TF\n", t, fl / t / 1e9);
@@ -39,11 +40,11 @@ int main(int argc, char** argv) {
     double t = time_gemm(g, 20); printf("dX plain         %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.aux = Y2; g.ldaux = W; g.aux_mode = AUX_MUL; g.colsum = cs; g.ldcs = W;
     t = time_gemm(g, 20); printf("dX aux+colsum    %.3f ms %.1f TF\n", t, fl / t / 1e9); }
-  for (int ns : {32, 48, 64}) { GemmArgs g; g.A = X; g.lda = W; g.a_ic = true; g.B = Y2; g.ldb = W; g.b_ic = true; g.I = W; g.J = W; g.K = P; g.C = dW; g.ldc = W;
+  for (int ns : {32, 48, 64}) { GemmArgs g; g.A = X; g.lda = W; g.a_ic = true; g.B = Y2; g.ldb = W; g.b_ic = true; g.I = W; g.J = W; g.K = P; g.C = dW; g.ldc = W; g.x6 = X6;
     g.k_split = ((P + ns - 1) / ns + 31) / 32 * 32; g.n_split = (P + g.k_split - 1) / g.k_split; g.slab_stride = (size_t)W * W;
     double t = time_gemm(g, 20); printf("dW split %d      %.3f ms %.1f TF\n", ns, t, fl / t / 1e9); }
   for (int div : {1, 2, 4, 8, 16}) {  // size sweep: fixed per-launch cost?
-    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P / div; g.J = W; g.K = W; g.C = Y; g.ldc = W;
+    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P / div; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6;
     double t = time_gemm(g, 40); printf("fwd plain I=P/%-2d  %.3f ms %.1f TF\n", div, t, fl / div / t / 1e9);
   }
 #ifdef SNERF_ABL_CLOCK
