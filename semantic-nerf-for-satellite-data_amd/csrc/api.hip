@@ -46,7 +46,7 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   if ((long long)d->n_rays * d->n_samples > (1ll << 30)) return bad("n_rays * n_samples too large for one pass (chunk the rays)");
   if (d->fc_layers < 1 || d->fc_layers > SNERF_MAX_LAYERS) return bad("fc_layers out of range");
   if (d->fc_units < 16 || (d->fc_units & 15)) return bad("fc_units must be a positive multiple of 16");
-  if (d->feat_last < 4 || (d->feat_last & 3) || d->feat_last > 64 * MAX_SKY_UNITS) return bad("feat_last must be a multiple of 4, <= 512");
+  if (d->feat_last < 8 || (d->feat_last & 7) || d->feat_last > 64 * MAX_SKY_UNITS) return bad("feat_last must be a multiple of 8, <= 512");
   if (d->n_freq < 0 || d->n_freq > 16) return bad("n_freq out of range");
   if (d->t_dim < 1 || d->t_dim > 16) return bad("t_dim out of range");
   if (d->n_classes < 0 || d->n_classes > MAX_CLASSES) return bad("n_classes out of range");
@@ -67,7 +67,7 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.sem_ts = sem && d->use_tj_for_s && sep_ts;
   p.sbeta_ts = sbeta && sep_ts;
   p.x_sun = 0; p.x_t = 3; p.x_ts = sep_ts ? 3 + p.tau : -1;
-  p.Xp = round_up(3 + p.tau + (sep_ts ? p.tau : 0), 4);
+  p.Xp = round_up(3 + p.tau + (sep_ts ? p.tau : 0), 16);  // FA % 16 == 0: weight planes are stored in 16-k tiles
   p.FA = p.W + p.Xp;
   int nb = 0;
   p.blk_rgb = nb++;
@@ -100,7 +100,8 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.t_s2 = take((size_t)p.H * p.H); p.t_s3 = take((size_t)p.H * p.H);
   p.t_s4 = take((size_t)p.H * NARROW);
   p.t_fin = take((size_t)p.KF * NARROW);
-  p.packed_floats = off;
+  p.n_fp32 = off;
+  p.packed_floats = off + round_up_sz((3 * off + 1) / 2, 64);
 
   // ---- workspace
   size_t wo = 0;
@@ -231,6 +232,17 @@ struct WS {
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
+// Weight operand of a K-contiguous GEMM: B = rows [row0, ...) and k >= k0 of the packed matrix at float offset `mat`
+// ([rows][ld]); attach the matrix's pre-split, k-tile-major bf16 planes (same element range in the plane region).
+static inline void weights(GemmArgs& g, const Plan& p, const float* pk, size_t mat, int rows, int ld, int row0 = 0, int k0 = 0) {
+  g.B = pk + mat + (size_t)row0 * ld + k0; g.ldb = ld;
+  g.x6 = p.x6;
+  if (p.x6) {
+    g.Bpl = reinterpret_cast<const unsigned short*>(pk + p.n_fp32) + mat; g.pl_stride = p.n_fp32;
+    g.bt_rows = rows; g.bt_row0 = row0; g.bt_k0 = k0; g.bt_elems = (size_t)rows * ld;
+  }
+}
+
 static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutputs* out, WS ws,
                         hipStream_t st) {
   const int P = p.P, W = p.W, H = p.H;
@@ -258,12 +270,11 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
     if (i == 0) { g.A = ws.f(p.o_pe); g.lda = p.Ep; }
     else if (skip) { g.A = ws.f(p.o_pe); g.lda = p.Ep; g.Ka = p.Ep; g.A2 = ws.f(p.o_h[i - 1]); g.lda2 = W; }
     else { g.A = ws.f(p.o_h[i - 1]); g.lda = W; }
-    g.B = pk + p.w_tr[i]; g.ldb = p.k_tr[i];
+    weights(g, p, pk, p.w_tr[i], W, p.k_tr[i]);
     g.I = P; g.J = W; g.K = p.k_tr[i];
     g.C = ws.f(p.o_h[i]); g.ldc = W;
     g.bias = pk + p.b_tr[i]; g.act = act; g.w0 = (p.siren && i == 0) ? 30.f : 1.f;
     g.C2 = (p.train && p.siren) ? ws.f(p.o_c[i]) : nullptr;
-    g.x6 = p.x6;
     RC(launch_gemm(g, st));
   }
   const float* hl = ws.f(p.o_h[p.L - 1]);
@@ -275,27 +286,27 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
   }
   {  // feats (rs_semantic.py:338), written into the first W columns of the [feats | sun | t | t_s] buffer
     GemmArgs g;
-    g.A = hl; g.lda = W; g.B = pk + p.w_fs; g.ldb = W; g.I = P; g.J = W; g.K = W;
-    g.C = ws.f(p.o_fa); g.ldc = p.FA; g.bias = pk + p.b_fs; g.x6 = p.x6;
+    g.A = hl; g.lda = W; weights(g, p, pk, p.w_fs, W + NARROW, W); g.I = P; g.J = W; g.K = W;
+    g.C = ws.f(p.o_fa); g.ldc = p.FA; g.bias = pk + p.b_fs;
     RC(launch_gemm(g, st));
   }
   {  // first layer of every head in one GEMM (sc pass: sun-visibility block only)
     GemmArgs g;
     g.A = ws.f(p.o_fa); g.lda = p.FA; g.I = P; g.K = p.FA;
     const size_t r0 = p.sc ? (size_t)p.blk_sun * H : 0;
-    g.B = pk + p.w_h1 + r0 * p.FA; g.ldb = p.FA; g.J = p.h1w;
+    weights(g, p, pk, p.w_h1, p.N1, p.FA, (int)r0); g.J = p.h1w;
     g.C = ws.f(p.o_h1); g.ldc = p.h1w; g.bias = pk + p.b_h1 + r0; g.act = act; g.w0 = 1.f;
-    g.C2 = (p.train && p.siren) ? ws.f(p.o_c1) : nullptr; g.x6 = p.x6;
+    g.C2 = (p.train && p.siren) ? ws.f(p.o_c1) : nullptr;
     RC(launch_gemm(g, st));
   }
   const int sun_col = p.sc ? 0 : p.blk_sun * H;
   {  // sun visibility layers 2,3 (rs_semantic.py:217-227)
     GemmArgs g;
-    g.A = ws.f(p.o_h1) + sun_col; g.lda = p.h1w; g.B = pk + p.w_s2; g.ldb = H; g.I = P; g.J = H; g.K = H;
-    g.C = ws.f(p.o_s2); g.ldc = H; g.bias = pk + p.b_s2; g.act = act; g.x6 = p.x6;
+    g.A = ws.f(p.o_h1) + sun_col; g.lda = p.h1w; weights(g, p, pk, p.w_s2, H, H); g.I = P; g.J = H; g.K = H;
+    g.C = ws.f(p.o_s2); g.ldc = H; g.bias = pk + p.b_s2; g.act = act;
     g.C2 = (p.train && p.siren) ? ws.f(p.o_cs2) : nullptr;
     RC(launch_gemm(g, st));
-    g.A = ws.f(p.o_s2); g.lda = H; g.B = pk + p.w_s3; g.bias = pk + p.b_s3; g.C = ws.f(p.o_s3);
+    g.A = ws.f(p.o_s2); g.lda = H; weights(g, p, pk, p.w_s3, H, H); g.bias = pk + p.b_s3; g.C = ws.f(p.o_s3);
     g.C2 = (p.train && p.siren) ? ws.f(p.o_cs3) : nullptr;
     RC(launch_gemm(g, st));
   }
@@ -391,7 +402,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(dw_reduce(p, ws, mf, (size_t)NARROW * p.KF, gp + p.w_fin, st));
     RC(bias_from_narrow(p, ws, dfin, gp + p.b_fin, st));
     GemmArgs g;  // dz1[:, :KF] = (dfin . W_fin) * act'
-    g.A = dfin; g.lda = NARROW; g.B = pk + p.t_fin; g.ldb = NARROW; g.I = P; g.J = p.KF; g.K = NARROW; g.x6 = p.x6;
+    g.A = dfin; g.lda = NARROW; weights(g, p, pk, p.t_fin, p.KF, NARROW); g.I = P; g.J = p.KF; g.K = NARROW;
     g.C = dz1; g.ldc = p.h1w; g.aux = dact(p.o_c1, p.o_h1); g.ldaux = p.h1w; g.aux_mode = aux_mode;
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));
@@ -404,20 +415,20 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(dw_reduce(p, ws, m4, (size_t)NARROW * H, gp + p.w_s4, st));
     RC(bias_from_narrow(p, ws, dsun, gp + p.b_s4, st));
     GemmArgs g;
-    g.A = dsun; g.lda = NARROW; g.B = pk + p.t_s4; g.ldb = NARROW; g.I = P; g.J = H; g.K = NARROW; g.x6 = p.x6;
+    g.A = dsun; g.lda = NARROW; weights(g, p, pk, p.t_s4, H, NARROW); g.I = P; g.J = H; g.K = NARROW;
     g.C = ws.f(p.o_dsa); g.ldc = H; g.aux = dact(p.o_cs3, p.o_s3); g.ldaux = H; g.aux_mode = aux_mode;
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));  // dz_s3
     RC(bias_from_colsum(p, ws, H, gp + p.b_s3, st));
     RC(dw_gemm(p, ws, mh, ws.f(p.o_dsa), H, H, false, ws.f(p.o_s2), H, H, 0, st));
     RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s3, st));
-    g.A = ws.f(p.o_dsa); g.lda = H; g.B = pk + p.t_s3; g.ldb = H; g.K = H;
+    g.A = ws.f(p.o_dsa); g.lda = H; weights(g, p, pk, p.t_s3, H, H); g.K = H;
     g.C = ws.f(p.o_dsb); g.aux = dact(p.o_cs2, p.o_s2);
     RC(launch_gemm(g, st));  // dz_s2
     RC(bias_from_colsum(p, ws, H, gp + p.b_s2, st));
     RC(dw_gemm(p, ws, mh, ws.f(p.o_dsb), H, H, false, ws.f(p.o_h1) + sun_col, p.h1w, H, 0, st));
     RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s2, st));
-    g.A = ws.f(p.o_dsb); g.B = pk + p.t_s2;
+    g.A = ws.f(p.o_dsb); weights(g, p, pk, p.t_s2, H, H);
     g.C = dz1 + sun_col; g.ldc = p.h1w; g.aux = dact(p.o_c1, p.o_h1) + sun_col; g.ldaux = p.h1w;
     RC(launch_gemm(g, st));  // dz1[:, sun block]
     RC(bias_from_colsum(p, ws, H, gp + p.b_h1 + (size_t)p.blk_sun * H, st));
@@ -429,7 +440,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(dw_gemm(p, ws, m1, dz1, p.h1w, p.h1w, false, ws.f(p.o_fa), p.FA, p.FA, 0, st));
     RC(dw_reduce(p, ws, m1, (size_t)p.h1w * p.FA, gp + p.w_h1 + r0 * p.FA, st));
     GemmArgs g;
-    g.A = dz1; g.lda = p.h1w; g.B = pk + p.t_h1 + r0; g.ldb = p.N1; g.x6 = p.x6;
+    g.A = dz1; g.lda = p.h1w; weights(g, p, pk, p.t_h1, p.FA, p.N1, 0, (int)r0);
     g.I = P; g.J = p.FA; g.K = p.h1w; g.C = dfa; g.ldc = p.FA;
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;  // columns [0,W) = bias grad of feats_from_xyz
     RC(launch_gemm(g, st));
@@ -447,7 +458,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(bias_from_narrow(p, ws, dsig, gp + p.b_fs + W, st));
     GemmArgs g;
     g.A = dfa; g.lda = p.FA; g.Ka = W; g.A2 = dsig; g.lda2 = NARROW;
-    g.B = pk + p.t_fs; g.ldb = W + NARROW; g.I = P; g.J = W; g.K = W + NARROW; g.x6 = p.x6;
+    weights(g, p, pk, p.t_fs, W, W + NARROW); g.I = P; g.J = W; g.K = W + NARROW;
     g.C = dz; g.ldc = W; g.aux = dact(p.o_c[p.L - 1], p.o_h[p.L - 1]); g.ldaux = W; g.aux_mode = aux_mode;
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));
@@ -465,7 +476,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(dw_reduce(p, ws, mt, (size_t)W * p.k_tr[i], gp + p.w_tr[i], st));
     if (i == 0) break;
     GemmArgs g;
-    g.A = dz_cur; g.lda = W; g.B = pk + p.t_tr[i]; g.ldb = W; g.x6 = p.x6;
+    g.A = dz_cur; g.lda = W; weights(g, p, pk, p.t_tr[i], W, W);
     g.I = P; g.J = W; g.K = W; g.C = dz_nxt; g.ldc = W;
     g.aux = dact(p.o_c[i - 1], p.o_h[i - 1]); g.ldaux = W; g.aux_mode = aux_mode;
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
@@ -520,7 +531,7 @@ int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* p
   build_tables(p, params, tb);
   if (tb.missing) { set_error("snerf_pack_params: a parameter tensor required by this SnerfDesc is NULL"); return SNERF_ERR_NULL; }
   hipStream_t st = (hipStream_t)stream;
-  SNERF_HIP_CHECK(hipMemsetAsync(packed, 0, p.packed_floats * sizeof(float), st));
+  SNERF_HIP_CHECK(hipMemsetAsync(packed, 0, p.n_fp32 * sizeof(float), st));
   for (int i = 0; i < tb.nt; ++i) RC(launch_copy_table(tb.tabs[i], packed, 0, st));
   // K-contiguous transposes consumed by the dX GEMMs
   for (int i = 1; i < p.L; ++i) {
@@ -533,6 +544,16 @@ int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* p
   RC(launch_transpose(packed + p.w_s3, p.H, p.H, p.H, packed + p.t_s3, p.H, st));
   RC(launch_transpose(packed + p.w_s4, p.H, NARROW, p.H, packed + p.t_s4, NARROW, st));
   RC(launch_transpose(packed + p.w_fin, p.KF, NARROW, p.KF, packed + p.t_fin, NARROW, st));
+  // pre-split, k-tile-major bf16 planes of every matrix that is the weight operand of a 128x128 GEMM
+  unsigned short* pl0 = reinterpret_cast<unsigned short*>(packed + p.n_fp32);
+  auto planes = [&](size_t mat, int rows, int ld) { return launch_split_planes(packed + mat, rows, ld, pl0 + mat, p.n_fp32, st); };
+  for (int i = 0; i < p.L; ++i) RC(planes(p.w_tr[i], p.W, p.k_tr[i]));
+  for (int i = 1; i < p.L; ++i) RC(planes(p.t_tr[i], p.W, p.W));
+  RC(planes(p.w_fs, p.W + NARROW, p.W)); RC(planes(p.t_fs, p.W, p.W + NARROW));
+  RC(planes(p.w_h1, p.N1, p.FA)); RC(planes(p.t_h1, p.FA, p.N1));
+  RC(planes(p.w_s2, p.H, p.H)); RC(planes(p.t_s2, p.H, p.H));
+  RC(planes(p.w_s3, p.H, p.H)); RC(planes(p.t_s3, p.H, p.H));
+  RC(planes(p.t_s4, p.H, NARROW)); RC(planes(p.t_fin, p.KF, NARROW));
   return SNERF_OK;
 }
 

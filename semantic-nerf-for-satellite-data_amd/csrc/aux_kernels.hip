@@ -149,6 +149,34 @@ int launch_transpose(const float* src, int ld_src, int rows, int cols, float* ds
   return 0;
 }
 
+// fp32 weight matrix [rows][ld] (ld % 16 == 0) -> three bf16 planes (hi | mid | lo, each the bf16 rounding of the
+// running residual: x = hi + mid + lo to 2^-26 relative), stored k-tile-major [ld/16][rows][16] with the LDS image's
+// swizzle baked in (the two 8-k halves of a row swap on rows with bit 3 set): a 128-row x 16-k tile is then 4 KB
+// of contiguous memory that the GEMM copies to LDS verbatim.  Plane p at planes + p*plane_stride.
+__global__ void split_planes_kernel(const float* __restrict__ x, int rows, int ld, unsigned short* __restrict__ planes,
+                                    size_t plane_stride) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)rows * ld) return;
+  const int r = (int)(i / ld), k = (int)(i - (size_t)r * ld);
+  const float v = x[i];
+  const __bf16 h = (__bf16)v;
+  const float r1 = v - (float)h;
+  const __bf16 m = (__bf16)r1;
+  const __bf16 l = (__bf16)(r1 - (float)m);
+  const int kk = k & 15;
+  const size_t o = ((size_t)(k >> 4) * rows + r) * 16 + ((((kk >> 3) ^ (r >> 3)) & 1) << 3) + (kk & 7);
+  planes[o] = __builtin_bit_cast(unsigned short, h);
+  planes[plane_stride + o] = __builtin_bit_cast(unsigned short, m);
+  planes[2 * plane_stride + o] = __builtin_bit_cast(unsigned short, l);
+}
+
+int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes, size_t plane_stride, hipStream_t st) {
+  const size_t n = (size_t)rows * ld;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, rows, ld, planes, plane_stride);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- slab reductions ---------------------------------------------------------------------------------
 // out[g][j] (+)= sum_{q in group g} in[q][j]; deterministic (fixed order), no atomics.
 __global__ void reduce_rows_kernel(const float* __restrict__ in, int n_in, size_t in_stride, int width,

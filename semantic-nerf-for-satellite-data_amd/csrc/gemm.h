@@ -33,6 +33,11 @@ struct GemmArgs {
   int k_split = 0; int n_split = 1; size_t slab_stride = 0;
   bool narrow_j = false;  // 128x32 tile (J <= 32-wide heads)
   bool narrow_i = false;  // 32x128 tile (dW of the narrow heads)
+  // pre-split B (weights): bf16 planes hi|mid|lo of the weight MATRIX that B points into, stored k-tile-major
+  // ([k/16][row][16], LDS swizzle baked in) so that one B tile is a contiguous 4 KB block per plane.
+  // Bpl = plane 0 of the matrix, plane p at Bpl + p*pl_stride elements; the operand is rows [bt_row0, +J) and
+  // k >= bt_k0 of a matrix with bt_rows rows.
+  const unsigned short* Bpl = nullptr; size_t pl_stride = 0; int bt_rows = 0, bt_row0 = 0, bt_k0 = 0; size_t bt_elems = 0;
   bool x6 = false;        // split-bf16 MFMA (gemm_x6.hip) for the 128x128 tile when both operands share a layout
 };
 

@@ -23,7 +23,7 @@
 
 namespace snerf {
 
-void launch_x6(bool ic, const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip
+void launch_x6(bool ic, bool b_planes, const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip
 
 template <int BI, bool IC>
 struct Tile {
@@ -241,12 +241,14 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
   p.bytesA = (unsigned)(g.a_ic ? ((size_t)(K1 - 1) * g.lda + g.I) * 4 : ((size_t)(g.I - 1) * g.lda + K1) * 4);
   p.bytesA2 = g.A2 ? (unsigned)(((size_t)(g.I - 1) * g.lda2 + (g.K - g.Ka)) * 4) : p.bytesA;
   p.bytesB = (unsigned)(g.b_ic ? ((size_t)(g.K - 1) * g.ldb + g.J) * 4 : ((size_t)(g.J - 1) * g.ldb + g.K) * 4);
+  p.Bpl = g.Bpl; p.pl_stride_bytes = (unsigned)(g.pl_stride * 2); p.bytesBpl = g.Bpl ? (unsigned)((2 * g.pl_stride + g.bt_elems) * 2) : 0;
+  p.bt_rows = g.bt_rows; p.bt_row0 = g.bt_row0; p.bt_k0 = g.bt_k0;
   p.act = g.act; p.aux_mode = g.aux ? g.aux_mode : AUX_NONE; p.w0 = g.w0;
   p.k_split = g.k_split; p.slab_stride = g.slab_stride;
   p.tiles_i = (g.I + BI - 1) / BI;
   p.tiles_j = (g.J + BJ - 1) / BJ;
   dim3 grid(p.tiles_i * p.tiles_j, 1, g.k_split > 0 ? g.n_split : 1);
-  if (g.x6 && BI == 128 && BJ == 128 && A_IC == B_IC) launch_x6(A_IC, p, grid, stream);
+  if (g.x6 && BI == 128 && BJ == 128 && A_IC == B_IC) launch_x6(A_IC, g.Bpl != nullptr && !A_IC, p, grid, stream);
   else hipLaunchKernelGGL((gemm_kernel<BI, BJ, WI, WJ, A_IC, B_IC>), grid, dim3(NT), 0, stream, p);
   SNERF_LAUNCH_CHECK();
   if (g_prof_on && rec.a && rec.b) {
@@ -307,6 +309,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
   if (g.b_ic) { if (g.J & 3) return bad("IC B needs J % 4 == 0"); }
   else { if (g.K & 3) return bad("KC B needs K % 4 == 0"); }
   if (g.k_split > 0 && (g.k_split % 32)) return bad("k_split must be a multiple of 32");
+  if (g.Bpl && ((g.bt_k0 & 15) || ((uintptr_t)g.Bpl & 15) || (g.pl_stride & 7) || g.bt_rows <= 0 || g.pl_stride * 6 >= 0xFFFFFFF0ull))
+    return bad("pre-split B planes need bt_k0 % 16 == 0 and 16-byte alignment");
   if (g.aux && g.aux_mode != AUX_NONE && g.ldaux <= 0) return bad("aux needs ldaux");
 
   if (!g.a_ic && !g.b_ic) {

@@ -26,6 +26,7 @@ struct KArgs {
   float* C; float* C2;
   const float* bias; const float* aux; float* colsum;
   unsigned bytesA, bytesA2, bytesB;
+  const unsigned short* Bpl; unsigned pl_stride_bytes; unsigned bytesBpl; int bt_rows, bt_row0, bt_k0;
   int lda, lda2, Ka, ldb, I, J, K, ldc, ldaux, ldcs;
   int act, aux_mode;
   float w0;

@@ -92,7 +92,9 @@ __device__ __forceinline__ bf16x8 load_frag(const char* __restrict__ pl, int r0,
   }
 }
 
-template <bool IC>
+// BPL: the B operand (weights) comes pre-split as bf16 planes (snerf_pack_params): each thread moves one 16-B chunk
+// (8 k of one row) per plane from global to LDS with no conversion work.
+template <bool IC, bool BPL>
 __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
   constexpr int MI = XWI / 32, NJ = XWJ / 32;
   constexpr int EPI_BYTES = epilogue_lds_floats(XWJ) * 4;
@@ -136,6 +138,13 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
   const unsigned stepB = IC ? (unsigned)p.ldb * 4u : 4u;
 
   float4 ra[2], rb[2];
+  u32x4 rbp[3];
+  const srd_t srdBp = make_srd(p.Bpl, p.bytesBpl);
+  // tile of k-tile kt = contiguous 4 KB per plane at ((bt_k0/16 + kt) * bt_rows + bt_row0 + j0) * 32 bytes; thread t moves
+  // chunk t (16 B).  Rows past the matrix end read the next k-tile's rows (or zeros past the buffer): those columns
+  // are >= J and masked in the epilogue.
+  const unsigned bp_base = ((unsigned)(p.bt_k0 >> 4) * (unsigned)p.bt_rows + (unsigned)(p.bt_row0 + j0)) * 32u + 16u * t;
+  const unsigned bp_step = (unsigned)p.bt_rows * 32u;   // bytes per k-tile
   // branch-free (the loop body must stay ONE basic block for the MFMA / VALU interleave below): the A segment
   // is chosen with scalar selects; beyond kEnd every lane's offset is out of bounds (zeros, no traffic)
   auto fetch = [&](int k0) {
@@ -148,14 +157,29 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
       const unsigned base = s2 ? la2.base[r] : la1.base[r];
       ra[r] = buf_load4(sA, (base != OOB && la1.kl[r] < kremA) ? base + kbA : OOB);
     }
-    lb1.load(rb, srdB, (unsigned)k0 * stepB, kEnd - k0);
+    if (BPL) {
+      const unsigned o = (k0 < kEnd) ? bp_base + (unsigned)((k0 - kBeg) >> 4) * bp_step + (unsigned)(kBeg >> 4) * bp_step : OOB;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        rbp[pl] = __builtin_amdgcn_raw_buffer_load_b128(srdBp, o == OOB ? OOB : o + pl * p.pl_stride_bytes, 0, 0);
+    } else {
+      lb1.load(rb, srdB, (unsigned)k0 * stepB, kEnd - k0);
+    }
+  };
+  auto store_b = [&](char* dst) {
+    if (BPL) {
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(dst + pl * PLANE_BYTES + 16 * t) = rbp[pl];
+    } else {
+      store_planes<IC>(rb, dst, t);
+    }
   };
   // Software pipeline: at the start of iteration kt the registers hold tile kt+1 (requested at the end of
   // iteration kt-1); it is split and stored into the idle LDS stage underneath the second half of this
   // iteration's MFMAs, then the loads of tile kt+2 are issued.
   fetch(kBeg);
   store_planes<IC>(ra, lds, t);
-  store_planes<IC>(rb, lds + OPERAND_BYTES, t);
+  store_b(lds + OPERAND_BYTES);
   fetch(kBeg + BK);
   __syncthreads();
 
@@ -191,7 +215,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
     for (int r = 0; r < 2; ++r) { asm volatile("" :: "v"(ra[r].x), "v"(ra[r].y), "v"(ra[r].z), "v"(ra[r].w)); asm volatile("" :: "v"(rb[r].x), "v"(rb[r].y), "v"(rb[r].z), "v"(rb[r].w)); }
 #elif !defined(SNERF_ABL_NOGLOAD)
     store_planes<IC>(ra, da, t);
-    store_planes<IC>(rb, da + OPERAND_BYTES, t);
+    store_b(da + OPERAND_BYTES);
 #endif
     block(1, 0);
     block(1, 1);
@@ -205,7 +229,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);          // 12 VALU
+      __builtin_amdgcn_sched_group_barrier(0x002, BPL ? 6 : 12, 0); // VALU slice
       __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);           // 1 DS write
     }
     __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);             // VMEM reads
@@ -220,9 +244,10 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
   gemm_epilogue<MI, NJ, XWJ>(acc, reinterpret_cast<float*>(lds), wave, lane, i0 + wi0, j0 + wj0, p, C);
 }
 
-void launch_x6(bool ic, const KArgs& p, dim3 grid, hipStream_t stream) {
-  if (ic) hipLaunchKernelGGL((gemm_x6_kernel<true>), grid, dim3(NT), 0, stream, p);
-  else hipLaunchKernelGGL((gemm_x6_kernel<false>), grid, dim3(NT), 0, stream, p);
+void launch_x6(bool ic, bool b_planes, const KArgs& p, dim3 grid, hipStream_t stream) {
+  if (ic) hipLaunchKernelGGL((gemm_x6_kernel<true, false>), grid, dim3(NT), 0, stream, p);
+  else if (b_planes) hipLaunchKernelGGL((gemm_x6_kernel<false, true>), grid, dim3(NT), 0, stream, p);
+  else hipLaunchKernelGGL((gemm_x6_kernel<false, false>), grid, dim3(NT), 0, stream, p);
 }
 
 }  // namespace snerf

@@ -43,7 +43,7 @@ def test_host_only_sizes_and_errors():
     d = spec.desc(4096, 64, _lib.FLAG_TRAIN)
     n = L.snerf_packed_floats(C.byref(d))
     # 2,826,766 parameters + padding of the packed layout + K-contiguous transposes for the dX GEMMs
-    assert 2 * 2_500_000 < n < 6_000_000
+    assert 2 * 2_500_000 < n < 15_000_000  # + three bf16 planes of the fp32 region
     train = L.snerf_workspace_bytes(C.byref(d))
     d.flags = 0
     infer = L.snerf_workspace_bytes(C.byref(d))
