@@ -183,21 +183,25 @@ def main():
     if prof is not None:
         from snerf_amd import ops as _ops
         x6 = (_ops.BASE_FLAGS & _lib.FLAG_FP32_MFMA) == 0
-        ms = sum(prof.ms[v] for v in range(3))
-        fl = sum(prof.flops[v] for v in range(3))
-        n = sum(prof.launches[v] for v in range(3))
+        # dominant kernel = variant 0: gemm_x6_kernel<false,true> (forward X.W^T and dX), ~62 % of device time
+        ms, fl, n = prof.ms[0], prof.flops[0], prof.launches[0]
         fp32_eq = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        fam_ms = sum(prof.ms[v] for v in range(3)); fam_fl = sum(prof.flops[v] for v in range(3))
         # split-bf16 kernel: the contraction at this accuracy IS six bf16 MFMA products per fp32 product, so the
         # kernel's algorithmic work is 6 x (2 I J K) bf16 flops, priced against the dense bf16 MFMA peak
         mult, peak = (6.0, BF16_MFMA_PEAK_TFLOPS) if x6 else (1.0, FP32_MFMA_PEAK_TFLOPS)
         achieved = fp32_eq * mult
+        # HBM bytes per launch of that kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+        # the MI355X guide), measured on this exact workload: profiles/r01/pmc_hbm_traffic.md
+        traffic = 1.684e9 if (x6 and args.rays == 4096 and args.samples == 64) else None
         line["roofline"] = {
-            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-            "kernel": ("snerf::gemm_x6_kernel<*> (split-bf16: 3 bf16 planes per fp32 operand, 6 x v_mfma_f32_32x32x16_bf16 per "
-                       "32x32x16 block, fp32 accumulate)" if x6 else
-                       "snerf::gemm_kernel<128,128,64,64,*,*> (v_mfma_f32_32x32x2_f32)"),
+            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+            "kernel": ("snerf::gemm_x6_kernel<false,true> (split-bf16: 3 bf16 planes per fp32 operand, 6 x v_mfma_f32_32x32x16_bf16 per "
+                       "32x32x16 block, fp32 accumulate; forward X.W^T and dX launches)" if x6 else
+                       "snerf::gemm_kernel<128,128,64,64,false,false> (v_mfma_f32_32x32x2_f32)"),
             "fp32_equivalent_tflops": fp32_eq, "vs_fp32_mfma_peak": fp32_eq / FP32_MFMA_PEAK_TFLOPS,
-            "launches": int(n), "avg_launch_ms": ms / max(n, 1), "gemm_ms_per_step": ms / args.steps,
+            "launches": int(n), "avg_launch_ms": ms / max(n, 1),
+            "all_128x128_gemms": {"ms_per_step": fam_ms / args.steps, "fp32_equivalent_tflops": fam_fl / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0},
             "per_variant": {(_lib.PROFILE_VARIANTS[v]): {
                 "launches": int(prof.launches[v]), "avg_ms": prof.ms[v] / max(prof.launches[v], 1),
                 "fp32_equivalent_tflops": (prof.flops[v] / (prof.ms[v] * 1e-3) / 1e12) if prof.ms[v] > 0 else 0.0}

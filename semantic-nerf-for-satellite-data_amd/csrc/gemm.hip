@@ -76,16 +76,19 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel(const KArgs p) {
   // store+fetch block, epilogue) run at raised priority; the MFMA phase at 0.
   __builtin_amdgcn_s_setprio(2);
   int ti, tj;
-  tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);
-  const int i0 = ti * BI, j0 = tj * BJ;
-
   int kBeg = 0, kEnd = p.K;
   float* C = p.C;
   if (p.k_split > 0) {
-    kBeg = blockIdx.z * p.k_split;
+    int tile, split;
+    split_tile_of_block(blockIdx.x, blockIdx.z, gridDim.x, gridDim.z, tile, split);
+    ti = tile / p.tiles_j; tj = tile - ti * p.tiles_j;
+    kBeg = split * p.k_split;
     kEnd = min(p.K, kBeg + p.k_split);
-    C += (size_t)blockIdx.z * p.slab_stride;
+    C += (size_t)split * p.slab_stride;
+  } else {
+    tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);
   }
+  const int i0 = ti * BI, j0 = tj * BJ;
   const int nkt = (kEnd - kBeg + BK - 1) / BK;
 
   f32x16 acc[MI][NJ];

@@ -52,6 +52,20 @@ __device__ __forceinline__ void tile_of_block(int b, int tiles_i, int tiles_j, i
   }
 }
 
+// Split-K launches (dW): grid = (tiles, 1, splits), dispatched x-fastest, so block f = x + tiles*z lands on XCD f % 8.
+// All tiles of one split read the same rows of dZ and X; remap so that one XCD group runs ALL tiles of a split
+// back to back (each operand block is then fetched from HBM once per split and shared through that L2).
+__device__ __forceinline__ void split_tile_of_block(int x, int z, int tiles, int splits, int& tile, int& split) {
+  const int s8 = splits & ~7;
+  tile = x; split = z;
+  if (z < s8) {
+    const int f = x + tiles * z;
+    const int xcd = f & 7, idx = f >> 3;
+    split = (idx / tiles) * 8 + xcd;
+    tile = idx - (idx / tiles) * tiles;
+  }
+}
+
 // thread -> (row, k) of its r-th float4 in a BI x BK k-tile (element e = t + NT*r of BI*BK/4).
 // KC: BK/4 lanes cover one row's BK floats; IC: BI/4 lanes cover one k-row.
 template <int BI, bool IC>

@@ -260,3 +260,30 @@ def test_ragged_and_multi_chunk_sizes():
             err = rel_err(gp[k].grad.cpu(), po[k].grad)
             assert err <= GRAD_REL_TOL or max_abs(gp[k].grad.cpu(), po[k].grad) <= 1e-7, (N, S, k, err)
         assert rel_err(emb_g.grad.cpu(), emb_o.grad) <= GRAD_REL_TOL
+
+
+def test_fp32_mfma_flag_path(monkeypatch):
+    """SNERF_FLAG_FP32_MFMA (plain v_mfma_f32_32x32x2_f32 kernels) gives the same results as the default split-bf16 path"""
+    from snerf_amd import ops, _lib
+    dev = _dev()
+    z, meta, cfg = load_fixture("sem_siren_small")
+    pn = fixture_params(z, meta, cfg)
+    b = fixture_batch(z)
+    emb = torch.from_numpy(O.init_embedding_numpy(cfg, meta["seed"]))
+    outs = {}
+    for name, flags in (("x6", 0), ("fp32", _lib.FLAG_FP32_MFMA)):
+        monkeypatch.setattr(ops, "BASE_FLAGS", flags)
+        gp = _gpu_params(pn, dev, requires_grad=True)
+        emb_g = emb.clone().to(dev).requires_grad_(True)
+        hip = _hip_render(cfg, gp, emb_g, b, dev)
+        hip.pop("_z_vals")
+        bg = {k: v.to(dev) for k, v in b.items()}
+        O.total_loss(O.training_losses(hip, bg, cfg, meta["epoch"])).backward()
+        outs[name] = (hip, {k: v.grad.clone() for k, v in gp.items()})
+        for k in z.files:
+            if k.startswith("out_") and k != "out_semantic_label_coarse":
+                assert max_abs(hip[k[4:]].detach().cpu(), z[k]) <= OUT_TOL, (name, k)
+    for k in outs["x6"][1]:
+        assert rel_err(outs["x6"][1][k].cpu(), outs["fp32"][1][k].cpu()) <= 1e-4 or \
+            max_abs(outs["x6"][1][k].cpu(), outs["fp32"][1][k].cpu()) <= 1e-8, k
+    assert max_abs(outs["x6"][0]["rgb_coarse"].detach().cpu(), outs["fp32"][0]["rgb_coarse"].detach().cpu()) <= 2e-6
