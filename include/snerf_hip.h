@@ -157,6 +157,10 @@ int snerf_unpack_grads(const SnerfDesc* desc, const float* packed_grads, const S
 int snerf_forward(const SnerfDesc* desc, const float* packed_params, const SnerfInputs* in,
                   const SnerfOutputs* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Stratified depths only (sample_rays, framework/components/rendering.py:95-110): z (N,S) from rays (N,8),
+ * z_steps (S) and an optional jitter tensor u (N,S).  Lets a caller share one z between passes on different streams. */
+int snerf_sample_z(const float* rays, const float* z_steps, const float* u, float* z, int n_rays, int n_samples, void* stream);
+
 /* Backward of one pass (what autograd does in the reference for the ops above): consumes the
  * activations that snerf_forward(SNERF_FLAG_TRAIN) left in `workspace`, ACCUMULATES parameter
  * gradients into packed_grads (caller zeroes it once per step) and writes d loss / d t (N,tau)

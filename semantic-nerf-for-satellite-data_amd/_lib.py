@@ -128,6 +128,8 @@ def lib():
     L.snerf_loss_finish.restype = C.c_int
     L.snerf_loss_finish.argtypes = [C.POINTER(SnerfLossCfg), C.POINTER(SnerfLossIn), C.c_void_p, C.c_float, C.c_float,
                                     C.c_void_p, C.POINTER(SnerfLossGrads), C.c_void_p]
+    L.snerf_sample_z.restype = C.c_int
+    L.snerf_sample_z.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.snerf_profile_begin.restype = C.c_int
     L.snerf_profile_end.restype = C.c_int
     L.snerf_profile_end.argtypes = [C.POINTER(SnerfProfile)]
@@ -145,4 +147,4 @@ def check(rc, what):
 EXPORTED_SYMBOLS = ("snerf_version", "snerf_last_error", "snerf_packed_floats", "snerf_workspace_bytes",
                     "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward", "snerf_test_gemm",
                     "snerf_loss_workspace_bytes", "snerf_loss_partial", "snerf_loss_finish", "snerf_profile_begin",
-                    "snerf_profile_end")
+                    "snerf_profile_end", "snerf_sample_z")

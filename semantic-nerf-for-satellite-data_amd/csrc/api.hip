@@ -595,6 +595,11 @@ int snerf_backward(const SnerfDesc* desc, const float* packed_params, const Sner
   return backward_impl(p, packed_params, in, gout, packed_grads, d_t, d_t_s, ws, (hipStream_t)stream);
 }
 
+int snerf_sample_z(const float* rays, const float* z_steps, const float* u, float* z, int n_rays, int n_samples, void* stream) {
+  if (!rays || !z_steps || !z || n_rays <= 0 || n_samples <= 0) { set_error("snerf_sample_z: bad argument"); return SNERF_ERR_NULL; }
+  return launch_sample_z(rays, z_steps, u, z, n_rays, n_samples, (hipStream_t)stream);
+}
+
 int snerf_profile_begin(void) { return profile_begin(); }
 int snerf_profile_end(SnerfProfile* out) { return profile_end(out); }
 

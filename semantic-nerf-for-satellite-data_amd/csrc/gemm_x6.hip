@@ -142,6 +142,9 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
 
   float4 ra[2], rb[2];
   u32x4 rbp[3];
+#ifdef SNERF_ABL_APLANES
+  u32x4 rap[3];
+#endif
   const srd_t srdBp = make_srd(p.Bpl, p.bytesBpl);
   // tile of k-tile kt = contiguous 4 KB per plane at ((bt_k0/16 + kt) * bt_rows + bt_row0 + j0) * 32 bytes; thread t moves
   // chunk t (16 B).  Rows past the matrix end read the next k-tile's rows (or zeros past the buffer): those columns
@@ -151,15 +154,23 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
   // branch-free (the loop body must stay ONE basic block for the MFMA / VALU interleave below): the A segment
   // is chosen with scalar selects; beyond kEnd every lane's offset is out of bounds (zeros, no traffic)
   auto fetch = [&](int k0) {
+#ifdef SNERF_ABL_APLANES
+    {
+      const unsigned o = (k0 < kEnd) ? ((unsigned)(k0 >> 4) * (unsigned)p.I + (unsigned)i0) * 32u + 16u * t : OOB;
+      for (int pl = 0; pl < 3; ++pl) rap[pl] = __builtin_amdgcn_raw_buffer_load_b128(srdA, o == OOB ? OOB : o + pl * ((unsigned)p.I * (unsigned)p.K * 2u / 3u & ~15u), 0, 0);
+    }
+#endif
     const bool s2 = k0 >= p.Ka;
     const srd_t sA = s2 ? srdA2 : srdA;
     const unsigned kbA = s2 ? (unsigned)(k0 - p.Ka) * 4u : (unsigned)k0 * stepA;
     const int kremA = s2 ? kEnd - k0 : min(kEnd, p.Ka) - k0;
+#ifndef SNERF_ABL_APLANES
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const unsigned base = s2 ? la2.base[r] : la1.base[r];
       ra[r] = buf_load4(sA, (base != OOB && la1.kl[r] < kremA) ? base + kbA : OOB);
     }
+#endif
     if (BPL) {
       const unsigned o = (k0 < kEnd) ? bp_base + (unsigned)((k0 - kBeg) >> 4) * bp_step + (unsigned)(kBeg >> 4) * bp_step : OOB;
 #pragma unroll
@@ -217,7 +228,11 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
 #if defined(SNERF_ABL_NOLDSSTORE)
     for (int r = 0; r < 2; ++r) { asm volatile("" :: "v"(ra[r].x), "v"(ra[r].y), "v"(ra[r].z), "v"(ra[r].w)); asm volatile("" :: "v"(rb[r].x), "v"(rb[r].y), "v"(rb[r].z), "v"(rb[r].w)); }
 #elif !defined(SNERF_ABL_NOGLOAD)
+#ifdef SNERF_ABL_APLANES
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(da + pl * PLANE_BYTES + 16 * t) = rap[pl];
+#else
     store_planes<IC>(ra, da, t);
+#endif
     store_b(da + OPERAND_BYTES);
 #endif
     block(1, 0);

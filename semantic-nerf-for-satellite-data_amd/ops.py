@@ -301,6 +301,19 @@ def render_pass(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Tensor,
     return out
 
 
+def sample_z(rays: torch.Tensor, z_steps: torch.Tensor, u: torch.Tensor | None) -> torch.Tensor:
+    """stratified depths (N,S) -- snerf_sample_z"""
+    L = _lib.lib()
+    _check_dev(rays, "rays")
+    rays = rays.contiguous()
+    N, S = rays.shape[0], z_steps.shape[0]
+    z = torch.empty((N, S), dtype=torch.float32, device=rays.device)
+    uc = u.contiguous() if u is not None else None
+    with torch.cuda.device(rays.device):
+        _lib.check(L.snerf_sample_z(_ptr(rays), _ptr(z_steps.contiguous()), _ptr(uc), _ptr(z), N, S, _stream()), "snerf_sample_z")
+    return z
+
+
 def test_gemm(A: torch.Tensor, B: torch.Tensor, a_ic: bool, b_ic: bool, I: int, J: int, K: int, narrow: int = 0):
     """C[I,J] = sum_k A(i,k) B(j,k) through the library's tiled MFMA kernel (test hook)."""
     L = _lib.lib()

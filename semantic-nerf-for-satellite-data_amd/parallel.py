@@ -48,22 +48,13 @@ def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
 
 
 def allreduce_gradients(params, flat_buffer: torch.Tensor = None) -> torch.Tensor:
-    """Sum-all-reduce every .grad through one flat bucket (a single RCCL call). Returns the bucket."""
+    """Sum-all-reduce every .grad through one flat bucket (a single RCCL call): one cat kernel in, one fused
+    multi-tensor copy out. Returns the bucket."""
     params = [p for p in params if p.grad is not None]
     if world()[1] == 1 or not params:
         return flat_buffer
-    n = sum(p.grad.numel() for p in params)
-    if flat_buffer is None or flat_buffer.numel() != n or flat_buffer.device != params[0].grad.device:
-        flat_buffer = torch.empty(n, dtype=params[0].grad.dtype, device=params[0].grad.device)
-    off = 0
-    for p in params:
-        k = p.grad.numel()
-        flat_buffer[off:off + k].copy_(p.grad.reshape(-1))
-        off += k
-    _all_reduce(flat_buffer)
-    off = 0
-    for p in params:
-        k = p.grad.numel()
-        p.grad.copy_(flat_buffer[off:off + k].view_as(p.grad))
-        off += k
-    return flat_buffer
+    grads = [p.grad for p in params]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    _all_reduce(flat)
+    torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+    return flat

@@ -4,12 +4,26 @@ ts -> int64 happens on the device (the reference round-trips through a CPU LongT
 values), the embedding lookup stays a torch op (its scatter-add backward gives the nn.Embedding
 gradient), and both passes -- main and, if sc_lambda > 0, the solar-correction pass on o + sun_d*z --
 run as fused HIP passes that share one packed copy of the weights."""
+import os
+
 import torch
 
 from ... import ops
 from ...framework.components.rendering import BaseRenderer, z_steps_on
 from ...framework.components.rays import extras_component_fn
 from ..models.rs_semantic import inference as rs_semantic_inference
+
+
+# main and solar-correction passes on two HIP streams (set SNERF_OVERLAP_SC=0 to serialise them)
+OVERLAP_SC_PASS = os.environ.get("SNERF_OVERLAP_SC", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 def fused_model_rendering(renderer, models, typ, rays, extras, render_options, inference_func, default_inference):
@@ -30,11 +44,32 @@ def fused_model_rendering(renderer, models, typ, rays, extras, render_options, i
         packed = ops.pack_params(model.spec, params)
     pin = ops.PassInputs(sun_d=sun_d, rays=rays, z_vals=opts.get("given_z_vals"),
                          z_steps=z_steps_on(rays.device, renderer.N_samples), u=opts.get("perturb_rand"))
-    result = ops.render_pass(model.spec, params, pin, rays_t, rays_t_s, packed=packed)
+    do_sc = cfgs.pipeline.sc_lambda > 0
+    z_given = opts.get("given_z_vals")
+    side = _side_stream(rays.device) if (do_sc and OVERLAP_SC_PASS) else None
+    if side is not None:
+        # The solar-correction pass only shares z_vals with the main pass.  Sample z first (tiny kernel), then run the
+        # two independent MLP passes on two HIP streams: their GEMM launches interleave on the CUs and fill each
+        # other's ramp-up / tail.  autograd replays each pass's backward on the stream of its forward.
+        if z_given is None:
+            z_given = ops.sample_z(rays, z_steps_on(rays.device, renderer.N_samples), opts.get("perturb_rand"))
+            pin = ops.PassInputs(sun_d=sun_d, rays=rays, z_vals=z_given)
+        main = torch.cuda.current_stream(rays.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            sc = ops.render_pass(model.spec, params, ops.PassInputs(sun_d=sun_d, rays=rays, z_vals=z_given), rays_t,
+                                 rays_t_s, sc_pass=True, packed=packed)
+        result = ops.render_pass(model.spec, params, pin, rays_t, rays_t_s, packed=packed)
+        main.wait_stream(side)
+        for v in sc.values():
+            v.record_stream(main)
+    else:
+        result = ops.render_pass(model.spec, params, pin, rays_t, rays_t_s, packed=packed)
+        if do_sc:
+            sc = ops.render_pass(model.spec, params, ops.PassInputs(sun_d=sun_d, rays=rays, z_vals=result["z_vals"]),
+                                 rays_t, rays_t_s, sc_pass=True, packed=packed)
     z_vals = result.pop("z_vals")
-    if cfgs.pipeline.sc_lambda > 0:
-        sc = ops.render_pass(model.spec, params, ops.PassInputs(sun_d=sun_d, rays=rays, z_vals=z_vals), rays_t, rays_t_s,
-                             sc_pass=True, packed=packed)
+    if do_sc:
         result["weights_sc"] = sc["weights"]
         result["transparency_sc"] = sc["transparency"]
         result["sun_sc"] = sc["sun"]

@@ -29,6 +29,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(Y2, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(Wt, h.data(), (size_t)W * W * 4, hipMemcpyHostToDevice));
+  unsigned short* Bplanes; CK(hipMalloc(&Bplanes, (size_t)3 * W * W * 2 + 4096)); CK(hipMemset(Bplanes, 0, (size_t)3 * W * W * 2));
   const double fl = 2.0 * P * W * W;
   { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6;
     double t = time_gemm(g, 20); printf("fwd plain        %.3f ms %.1f TF\n", t, fl / t / 1e9);
@@ -45,6 +46,7 @@ int main(int argc, char** argv) {
     double t = time_gemm(g, 20); printf("dW split %d      %.3f ms %.1f TF\n", ns, t, fl / t / 1e9); }
   for (int div : {1, 2, 4, 8, 16}) {  // size sweep: fixed per-launch cost?
     GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P / div; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6;
+    if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; }
     double t = time_gemm(g, 40); printf("fwd plain I=P/%-2d  %.3f ms %.1f TF\n", div, t, fl / div / t / 1e9);
   }
 #ifdef SNERF_ABL_CLOCK
