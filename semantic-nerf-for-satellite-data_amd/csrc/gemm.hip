@@ -103,7 +103,10 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel(const KArgs p) {
   // partially covered tiles compute on zero-filled LDS rows and mask the stores instead.
   const bool wave_live = (i0 + wi0 < p.I) && (j0 + wj0 < p.J);
 
-  const srd_t srdA = make_srd(p.A, p.bytesA), srdA2 = make_srd(p.A2, p.bytesA2), srdB = make_srd(p.B, p.bytesB);
+  const int Ka1 = min(p.Ka, p.K);  // length of the first A segment
+  const srd_t srdA = A_IC ? srd_krows(p.A, p.lda, kBeg, kEnd, p.I) : srd_rows(p.A, p.lda, i0, p.I, Ka1);
+  const srd_t srdA2 = srd_rows(p.A2, p.lda2, i0, p.I, p.K - Ka1);
+  const srd_t srdB = B_IC ? srd_krows(p.B, p.ldb, kBeg, kEnd, p.J) : srd_rows(p.B, p.ldb, j0, p.J, p.K);
   Loader<BI, A_IC> la1, la2;
   Loader<BJ, B_IC> lb1;
   la1.init(t, i0, p.I, p.lda);
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel(const KArgs p) {
   float4 ra[TA::NV], rb[TB::NV];
   // k-tiles never straddle the two A segments (Ka % BK == 0, checked on the host)
   auto fetch = [&](int k0) {
-    if (k0 < p.Ka) la1.load(ra, srdA, (unsigned)k0 * stepA, min(kEnd, p.Ka) - k0);
+    if (k0 < p.Ka) la1.load(ra, srdA, (unsigned)(A_IC ? k0 - kBeg : k0) * stepA, min(kEnd, p.Ka) - k0);
     else la2.load(ra, srdA2, (unsigned)(k0 - p.Ka) * 4u, kEnd - k0);
-    lb1.load(rb, srdB, (unsigned)k0 * stepB, kEnd - k0);
+    lb1.load(rb, srdB, (unsigned)(B_IC ? k0 - kBeg : k0) * stepB, kEnd - k0);
   };
   // Software pipeline (one register set, two LDS stages): at the start of iteration kt the registers hold
   // tile kt+1 (loaded during iteration kt-1, so its vmcnt wait is free); they are written to the LDS stage that
@@ -303,10 +306,9 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
   if (g.bias && ((uintptr_t)g.bias & 15)) return bad("bias must be 16-byte aligned");
   if (g.aux && (((uintptr_t)g.aux & 15) || (g.ldaux & 3))) return bad("aux must be 16-byte aligned with ldaux % 4 == 0");
   if (g.colsum && (((uintptr_t)g.colsum & 15) || (g.ldcs & 3))) return bad("colsum must be 16-byte aligned with ldcs % 4 == 0");
-  const size_t lim = 0xFFFFFFF0ull / 4;  // floats addressable through a 32-bit buffer offset
-  if ((size_t)(g.a_ic ? g.K : g.I) * g.lda >= lim) return bad("A operand exceeds 4 GiB: render fewer rays per pass");
-  if (g.A2 && (size_t)g.I * g.lda2 >= lim) return bad("A2 operand exceeds 4 GiB");
-  if ((size_t)(g.b_ic ? g.K : g.J) * g.ldb >= lim) return bad("B operand exceeds 4 GiB: render fewer rays per pass");
+  if ((size_t)128 * g.lda >= 0x3FFFFFFFull || (size_t)128 * g.ldb >= 0x3FFFFFFFull) return bad("leading dimension too large");
+  if (g.k_split > 0 && ((size_t)g.k_split * g.lda >= 0x3FFFFFFFull || (size_t)g.k_split * g.ldb >= 0x3FFFFFFFull)) return bad("k_split * ld exceeds the 32-bit tile span");
+  if (g.a_ic && g.k_split == 0 && (size_t)g.K * g.lda >= 0x3FFFFFFFull) return bad("row-contiguous operand without split-K exceeds the 32-bit span");
   if (g.a_ic) { if (g.I & 3) return bad("IC A needs I % 4 == 0"); if (g.A2) return bad("two-segment A is KC only"); }
   else { if (g.K & 3) return bad("KC A needs K % 4 == 0"); if (g.A2 && (g.Ka % BK)) return bad("Ka must be a multiple of 16"); }
   if (g.b_ic) { if (g.J & 3) return bad("IC B needs J % 4 == 0"); }

@@ -83,24 +83,25 @@ __device__ __forceinline__ bool tile_coord(int t, int r, int& il, int& kl) {
   return e < BI * BK / 4;
 }
 
-// per-thread loader state of one operand: byte offsets of its float4s at k = 0 (OOB if the row is outside)
+// per-thread loader state of one operand.  Offsets are relative to a per-workgroup descriptor base (the tile's
+// first row for KC operands, the K-split's first k-row for IC operands), so 32-bit offsets never span more than one
+// tile / one split however large the operand is.
 template <int BI, bool IC>
 struct Loader {
   static constexpr int NV = (BI * BK / 4 + NT - 1) / NT;
-  unsigned base[NV];
+  unsigned base[NV];  // byte offset of the float4 at the first k of the range, or OOB if its row is outside
   int kl[NV];
   __device__ __forceinline__ void init(int t, int i0, int I, int ld) {
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
       int il, k;
       const bool in = tile_coord<BI, IC>(t, r, il, k);
-      const int i = i0 + il;
       kl[r] = k;
-      const unsigned o = IC ? ((unsigned)k * (unsigned)ld + (unsigned)i) * 4u : ((unsigned)i * (unsigned)ld + (unsigned)k) * 4u;
-      base[r] = (in && i < I) ? o : OOB;
+      const unsigned o = IC ? ((unsigned)k * (unsigned)ld + (unsigned)(i0 + il)) * 4u : ((unsigned)il * (unsigned)ld + (unsigned)k) * 4u;
+      base[r] = (in && i0 + il < I) ? o : OOB;
     }
   }
-  // kbytes: byte offset of the tile's first k inside the segment; krem: valid k's left in the segment
+  // kbytes: byte offset of the tile's first k relative to the descriptor base; krem: valid k's left
   __device__ __forceinline__ void load(float4 (&v)[NV], srd_t srd, unsigned kbytes, int krem) const {
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
@@ -109,6 +110,19 @@ struct Loader {
     }
   }
 };
+
+// descriptor of a K-contiguous operand (element (i,k) at P[i*ld + k]) based at row i0
+__device__ __forceinline__ srd_t srd_rows(const float* P, int ld, int i0, int I, int Kseg) {
+  const long long rows = (long long)I - i0;
+  const unsigned long long bytes = rows > 0 ? ((unsigned long long)(rows - 1) * ld + Kseg) * 4ull : 0ull;
+  return make_srd(P + (size_t)i0 * ld, (unsigned)(bytes < 0xFFFFFFF0ull ? bytes : 0xFFFFFFF0ull));
+}
+// descriptor of a row-contiguous operand (element (i,k) at P[k*ld + i]) based at k-row kBeg
+__device__ __forceinline__ srd_t srd_krows(const float* P, int ld, int kBeg, int kEnd, int I) {
+  const long long ks = (long long)kEnd - kBeg;
+  const unsigned long long bytes = ks > 0 ? ((unsigned long long)(ks - 1) * ld + I) * 4ull : 0ull;
+  return make_srd(P + (size_t)kBeg * ld, (unsigned)(bytes < 0xFFFFFFF0ull ? bytes : 0xFFFFFFF0ull));
+}
 
 // Fused epilogue.  C/D layout of the 32x32 MFMA (fp32 and bf16 forms alike): col = lane & 31,
 // row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  Each wave transposes its 32-row accumulator blocks through

@@ -131,7 +131,10 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
 
   const bool wave_live = (i0 + wi0 < p.I) && (j0 + wj0 < p.J);
 
-  const srd_t srdA = make_srd(p.A, p.bytesA), srdA2 = make_srd(p.A2, p.bytesA2), srdB = make_srd(p.B, p.bytesB);
+  const int Ka1 = min(p.Ka, p.K);  // length of the first A segment
+  const srd_t srdA = IC ? srd_krows(p.A, p.lda, kBeg, kEnd, p.I) : srd_rows(p.A, p.lda, i0, p.I, Ka1);
+  const srd_t srdA2 = srd_rows(p.A2, p.lda2, i0, p.I, p.K - Ka1);
+  const srd_t srdB = IC ? srd_krows(p.B, p.ldb, kBeg, kEnd, p.J) : srd_rows(p.B, p.ldb, j0, p.J, p.K);
   Loader<XBI, IC> la1, la2;
   Loader<XBJ, IC> lb1;
   la1.init(t, i0, p.I, p.lda);
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
 #endif
     const bool s2 = k0 >= p.Ka;
     const srd_t sA = s2 ? srdA2 : srdA;
-    const unsigned kbA = s2 ? (unsigned)(k0 - p.Ka) * 4u : (unsigned)k0 * stepA;
+    const unsigned kbA = s2 ? (unsigned)(k0 - p.Ka) * 4u : (unsigned)(IC ? k0 - kBeg : k0) * stepA;
     const int kremA = s2 ? kEnd - k0 : min(kEnd, p.Ka) - k0;
 #ifndef SNERF_ABL_APLANES
 #pragma unroll
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_x6_kernel(const KArgs p) {
       for (int pl = 0; pl < 3; ++pl)
         rbp[pl] = __builtin_amdgcn_raw_buffer_load_b128(srdBp, o == OOB ? OOB : o + pl * p.pl_stride_bytes, 0, 0);
     } else {
-      lb1.load(rb, srdB, (unsigned)k0 * stepB, kEnd - k0);
+      lb1.load(rb, srdB, (unsigned)(IC ? k0 - kBeg : k0) * stepB, kEnd - k0);
     }
   };
   auto store_b = [&](char* dst) {

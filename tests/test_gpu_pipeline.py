@@ -277,3 +277,25 @@ def test_data_parallel_step_equals_single_process(tmp_path, monkeypatch):
     assert abs(ddp["loss"] - float(out["loss"])) <= 1e-5 * max(1.0, abs(float(out["loss"])))
     for n, g in single.items():
         assert rel_err(ddp["grads"][n], g) <= 1e-4 or max_abs(ddp["grads"][n], g) <= 1e-8, (n, rel_err(ddp["grads"][n], g))
+
+
+def test_full_frame_inference_chunk_beyond_4gib():
+    """eval path (eval/utils/util.py:13-42) at the reference's default render_chunk_size = 40960 rays x 64 samples:
+    2.6 M points per pass, hidden activations > 4 GiB per tensor (per-workgroup buffer descriptors, no 32-bit limit);
+    must equal the same rays rendered in small chunks."""
+    from snerf_amd.eval.utils.util import batched_inference
+    cfg = O.OracleCfg(fc_units=512, n_samples=64, render_chunk_size=40960)
+    pipe, _ = _pipeline_for(cfg, 1024, 2)
+    N = 40960
+    bank = O.batch_to_torch(O.synthetic_batch(N, 64, seed=33))
+    rays, extras, u = bank["rays"].to(DEV), bank["extras"].to(DEV), bank["u"].to(DEV)
+    big = batched_inference(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, render_options={"perturb_rand": u})
+    assert big["rgb_coarse"].shape == (N, 3) and bool(torch.isfinite(big["rgb_coarse"]).all())
+    idx = torch.arange(0, N, 37, device=DEV)[:512]
+    with torch.no_grad():
+        small = pipe.renderer.render_rays(pipe.models, rays[idx], extras[idx], render_options={"perturb_rand": u[idx]})
+    for k in ("rgb_coarse", "depth_coarse", "semantic_logits_coarse", "weights_coarse"):
+        assert max_abs(big[k][idx].cpu(), small[k].cpu()) <= 1e-6, k
+    assert torch.equal(big["semantic_label_coarse"][idx], small["semantic_label_coarse"])
+    del big
+    torch.cuda.empty_cache()
