@@ -34,7 +34,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "P
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
-def make_cfgs(rays_per_gpu, samples, world):
+def make_cfgs(rays_per_gpu, samples, world, mfma="split3"):
     from snerf_amd.framework.configs import MainConfig
     pipeline = {
         "pipeline": "snerf_amd.semantic.pipelines.rs_semantic.RSSemanticPipeline",
@@ -45,7 +45,7 @@ def make_cfgs(rays_per_gpu, samples, world):
         "lambda_s": 0.04, "semantic_activation_function": "sigmoid", "ignore_car_index": True,
         # steady state of training: beta loss active (epoch >= first_beta_epoch), depth rays dropped
         # (after 25 % of the steps, baseline/pipelines/satnerf.py:26-29) -- SURVEY.md 8(d)
-        "first_beta_epoch": 0, "depth_enabled": False,
+        "first_beta_epoch": 0, "depth_enabled": False, "mfma_precision": mfma,
     }
     run = {"max_train_steps": 1 << 30, "synthetic_rays": max(1 << 20, rays_per_gpu * world * 4), "synthetic_images": 19,
            "synthetic_seed": 0, "shuffle_dataset": True}
@@ -118,6 +118,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-GEMM HIP-event timing")
     ap.add_argument("--serial-passes", action="store_true", help="run main and sc pass on one stream (as the roofline phase does)")
+    ap.add_argument("--mfma", default="split3", choices=["split3", "fp32", "split2", "bf16"],
+                    help="matrix arithmetic: split3 = fp32-class (headline, default); split2 / bf16 are the REDUCED-precision "
+                         "modes of BASELINE configs[2]/[4] (reported under their own dtype, never as the fp32 headline)")
     ap.add_argument("--eager-gpu-baseline", action="store_true", help="also time the oracle with stock PyTorch ops on the GPU")
     args = ap.parse_args()
 
@@ -136,7 +139,7 @@ def main():
         from snerf_amd.semantic.components import rendering as _r0
         _r0.OVERLAP_SC_PASS = False
     torch.manual_seed(0)
-    cfgs = make_cfgs(args.rays, args.samples, world)
+    cfgs = make_cfgs(args.rays, args.samples, world, args.mfma)
     pipe = load_pipeline(cfgs)
     pipe.log_metrics = False  # the reference logs per-step scalars lazily; no host sync inside the timed region
     loop = TrainLoop(pipe, cfgs, device)
@@ -187,8 +190,7 @@ def main():
 
     if rank != 0:
         return
-    from snerf_amd import ops as _ops2
-    ops_flags = _ops2.BASE_FLAGS
+    mode = pipe.models["coarse"].spec.mfma
     rays_total = args.rays * world * args.steps
     value = rays_total / dt
     flops_step_gpu = FLOPS_PER_SAMPLE_TRAIN * args.rays * args.samples
@@ -196,8 +198,10 @@ def main():
         "metric": "train rays/sec (4096 rays x 64 samples)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (fp32 storage and accumulate; products on bf16 MFMA via 3-plane splits, fp32-level accuracy)"
-                 if (ops_flags & _lib.FLAG_FP32_MFMA) == 0 else "f32", "data": "synthetic",
+        "dtype": {"split3": "f32 (fp32 storage and accumulate; products on bf16 MFMA via 3-plane splits, fp32-level accuracy)",
+                  "fp32": "f32", "split2": "REDUCED: f32 storage/accumulate, operands as 2 bf16 planes (~16 bits, torch 'high')",
+                  "bf16": "REDUCED: bf16 operands, f32 accumulate and storage (torch 'medium' / precision=16)"}[mode],
+        "data": "synthetic",
         "config": {"workload": "JAX_068 semantic pipeline (configs[1]): RSSemanticNeRF fc_units=512 x 8 layers, C=5, "
                                f"{args.rays} rays x {args.samples} samples per GPU, fp32, main + solar-correction pass, "
                                "SatNerfLoss + sc + SemanticLoss(ignore car), Adam lr 5e-4; synthetic rays (SURVEY 8d), "
@@ -208,19 +212,18 @@ def main():
     }
     step_tflops = flops_step_gpu * args.steps / dt / 1e12  # per GPU, algorithmic (SURVEY 8d figure)
     if prof is not None:
-        from snerf_amd import ops as _ops
-        x6 = (_ops.BASE_FLAGS & _lib.FLAG_FP32_MFMA) == 0
+        x6 = mode != "fp32"
         # dominant kernel = variant 0: gemm_x6_kernel<false,true> (forward X.W^T and dX), ~62 % of device time
         ms, fl, n = prof.ms[0], prof.flops[0], prof.launches[0]
         fp32_eq = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         fam_ms = sum(prof.ms[v] for v in range(3)); fam_fl = sum(prof.flops[v] for v in range(3))
         # split-bf16 kernel: the contraction at this accuracy IS six bf16 MFMA products per fp32 product, so the
         # kernel's algorithmic work is 6 x (2 I J K) bf16 flops, priced against the dense bf16 MFMA peak
-        mult, peak = (6.0, BF16_MFMA_PEAK_TFLOPS) if x6 else (1.0, FP32_MFMA_PEAK_TFLOPS)
+        mult, peak = ({"split3": 6.0, "split2": 3.0, "bf16": 1.0}[mode], BF16_MFMA_PEAK_TFLOPS) if x6 else (1.0, FP32_MFMA_PEAK_TFLOPS)
         achieved = fp32_eq * mult
         # HBM bytes per launch of that kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
         # the MI355X guide), measured on this exact workload: profiles/r01/pmc_hbm_traffic.md
-        traffic = 1.684e9 if (x6 and args.rays == 4096 and args.samples == 64) else None
+        traffic = 1.684e9 if (mode == "split3" and args.rays == 4096 and args.samples == 64) else None
         line["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
             "kernel": ("snerf::gemm_x6_kernel<false,true> (split-bf16: 3 bf16 planes per fp32 operand, 6 x v_mfma_f32_32x32x16_bf16 per "

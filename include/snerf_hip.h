@@ -49,6 +49,11 @@ extern "C" {
                                   split-bf16 form (three bf16 planes per fp32 operand, six v_mfma_f32_32x32x16_bf16
                                   products, fp32 accumulate: same accuracy class, 2.7x less matrix-pipe time) */
 
+#define SNERF_FLAG_BF16 8u     /* REDUCED precision (the reference's `precision = 16` runs; BASELINE.json configs[2], [4]):
+                                  operands rounded to one bf16 plane, one MFMA product, fp32 accumulate, fp32 storage.
+                                  Judged on PSNR / mIoU, not on the 1e-4 parity bar. */
+#define SNERF_FLAG_BF16X3 16u  /* REDUCED precision: two bf16 planes (hi | mid), products hh + hm + mh: ~16 significant bits */
+
 /* Model + batch description.  Field names follow the reference config
  * (configs/pipelines/rs_semantic.toml:13-67, semantic/pipelines/rs_semantic.py:125-141). */
 typedef struct SnerfDesc {

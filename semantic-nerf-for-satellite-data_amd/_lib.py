@@ -9,6 +9,10 @@ MAX_LAYERS = 16
 FLAG_TRAIN = 1
 FLAG_SC_PASS = 2
 FLAG_FP32_MFMA = 4  # contract on v_mfma_f32_32x32x2_f32 instead of the default split-bf16 (x6) form
+FLAG_BF16 = 8       # reduced precision: one bf16 plane per operand (precision = 16 / float32_matmul_precision "medium")
+FLAG_BF16X3 = 16    # reduced precision: two bf16 planes, three products (float32_matmul_precision "high")
+# ModelSpec.mfma -> SnerfDesc.flags
+MFMA_FLAGS = {"split3": 0, "fp32": FLAG_FP32_MFMA, "split2": FLAG_BF16X3, "bf16": FLAG_BF16}
 
 _fp = C.POINTER(C.c_float)
 

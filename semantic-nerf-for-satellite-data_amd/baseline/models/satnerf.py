@@ -72,4 +72,4 @@ class SatNeRF(_NerfBase):
         self._build_shadow_heads(feat, self.feat_last, siren, t_embedding_dims, nl)
         self.spec = ops.ModelSpec(fc_units=feat, fc_layers=layers, feat_last=self.feat_last, fc_skips=tuple(skips),
                                   n_freq=n_freq, siren=bool(siren), t_dim=t_embedding_dims, n_classes=0,
-                                  sem_sigmoid=False)
+                                  sem_sigmoid=False, mfma=ops.mfma_mode(cfgs.pipeline, getattr(cfgs, "run", None)))

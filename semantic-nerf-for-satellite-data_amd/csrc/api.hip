@@ -26,7 +26,8 @@ void set_error(const char* fmt, ...) {
 // at least 512 contraction rows per split, at most 256 splits.  All GEMMs that fill one matrix
 // (e.g. the [gamma | h] column segments of a skip layer) share the choice made for the widest of them.
 DwSplit dw_choose(int P, int rows, int cols, bool narrow_rows) {
-  const int tiles = (narrow_rows ? 1 : (rows + 127) / 128) * ((cols + 127) / 128);
+  // whole 128-row blocks only: a 32-row tail (the sigma rows riding on a trunk matrix) is its own narrow launch
+  const int tiles = (narrow_rows || rows < 128 ? 1 : rows / 128) * ((cols + 127) / 128);
   int ns = (1024 + tiles / 2) / tiles;
   const int ns_max = P / 512 > 1 ? P / 512 : 1;
   if (ns > ns_max) ns = ns_max;
@@ -58,6 +59,8 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.siren = d->siren != 0; p.sem_sigmoid = d->sem_sigmoid != 0;
   p.train = (d->flags & SNERF_FLAG_TRAIN) != 0; p.sc = (d->flags & SNERF_FLAG_SC_PASS) != 0;
   p.x6 = (d->flags & SNERF_FLAG_FP32_MFMA) == 0;
+  p.planes = (d->flags & SNERF_FLAG_BF16) ? 1 : ((d->flags & SNERF_FLAG_BF16X3) ? 2 : 3);
+  if (!p.x6 && p.planes != 3) return bad("SNERF_FLAG_FP32_MFMA excludes the bf16 flags");
   p.skip_mask = d->skip_mask;
   const bool sem = p.C > 0;
   const bool sbeta = sem && d->use_separate_beta_for_s;
@@ -236,7 +239,7 @@ struct WS {
 // ([rows][ld]); attach the matrix's pre-split, k-tile-major bf16 planes (same element range in the plane region).
 static inline void weights(GemmArgs& g, const Plan& p, const float* pk, size_t mat, int rows, int ld, int row0 = 0, int k0 = 0) {
   g.B = pk + mat + (size_t)row0 * ld + k0; g.ldb = ld;
-  g.x6 = p.x6;
+  g.x6 = p.x6; g.planes = p.planes;
   if (p.x6) {
     g.Bpl = reinterpret_cast<const unsigned short*>(pk + p.n_fp32) + mat; g.pl_stride = p.n_fp32;
     g.bt_rows = rows; g.bt_row0 = row0; g.bt_k0 = k0; g.bt_elems = (size_t)rows * ld;
@@ -355,7 +358,7 @@ static int dw_gemm(const Plan& p, WS ws, const DwMat& m, const float* dz, int ld
   g.A = dz; g.lda = lddz; g.a_ic = true; g.B = X; g.ldb = ldx; g.b_ic = true;
   g.I = I; g.J = J; g.K = p.P;
   g.C = ws.f(p.o_slab) + slab_off; g.ldc = m.ldw;
-  g.k_split = m.sp.k_split; g.n_split = m.sp.ns; g.slab_stride = m.stride; g.narrow_i = narrow_i; g.x6 = p.x6;
+  g.k_split = m.sp.k_split; g.n_split = m.sp.ns; g.slab_stride = m.stride; g.narrow_i = narrow_i; g.x6 = p.x6; g.planes = p.planes;
   return launch_gemm(g, st);
 }
 static int dw_reduce(const Plan& p, WS ws, const DwMat& m, size_t count, float* gout, hipStream_t st) {
@@ -609,6 +612,8 @@ int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, 
   g.A = A; g.lda = lda; g.a_ic = a_ic != 0; g.B = B; g.ldb = ldb; g.b_ic = b_ic != 0;
   g.C = C; g.ldc = ldc; g.I = I; g.J = J; g.K = K;
   g.narrow_j = (narrow & 3) == 1; g.narrow_i = (narrow & 3) == 2; g.x6 = (narrow & 4) != 0;
+  g.planes = (narrow & 8) ? 1 : ((narrow & 16) ? 2 : 3);
+  g.tile = (narrow & 32) ? 256 : ((narrow & 64) ? 128 : 0);
   return launch_gemm(g, (hipStream_t)stream);
 }
 

@@ -38,8 +38,17 @@ struct GemmArgs {
   // Bpl = plane 0 of the matrix, plane p at Bpl + p*pl_stride elements; the operand is rows [bt_row0, +J) and
   // k >= bt_k0 of a matrix with bt_rows rows.
   const unsigned short* Bpl = nullptr; size_t pl_stride = 0; int bt_rows = 0, bt_row0 = 0, bt_k0 = 0; size_t bt_elems = 0;
+  int tile = 0;           // split kernel tile: 128, 256, or 0 = choose (256 when it wastes no more area than 128)
+  int planes = 3;         // bf16 planes per operand of the split kernel: 3 fp32-class, 2 ~16-bit, 1 plain bf16
   bool x6 = false;        // split-bf16 MFMA (gemm_x6.hip) for the 128x128 tile when both operands share a layout
 };
+
+// tile of the split kernel for an I x J problem: 256 x 256 when that covers no more padded area than 128 x 128
+inline int x6_tile(int I, int J) {
+  const long long a128 = (long long)((I + 127) / 128) * ((J + 127) / 128) * 128 * 128;
+  const long long a256 = (long long)((I + 255) / 256) * ((J + 255) / 256) * 256 * 256;
+  return a256 <= a128 ? 256 : 128;
+}
 
 int launch_gemm(const GemmArgs& g, hipStream_t stream);
 int profile_begin();

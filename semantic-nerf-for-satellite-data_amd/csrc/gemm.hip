@@ -23,7 +23,7 @@
 
 namespace snerf {
 
-void launch_x6(bool ic, bool b_planes, const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip
+void launch_x6(bool ic, bool b_planes, int planes, int tile, const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip
 
 template <int BI, bool IC>
 struct Tile {
@@ -254,7 +254,20 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
   p.tiles_i = (g.I + BI - 1) / BI;
   p.tiles_j = (g.J + BJ - 1) / BJ;
   dim3 grid(p.tiles_i * p.tiles_j, 1, g.k_split > 0 ? g.n_split : 1);
-  if (g.x6 && BI == 128 && BJ == 128 && A_IC == B_IC) launch_x6(A_IC, g.Bpl != nullptr && !A_IC, p, grid, stream);
+  if (g.x6 && BI == 128 && BJ == 128 && A_IC == B_IC) {
+    int tile = g.tile;
+    if (tile != 128 && tile != 256) {
+      static const int forced = getenv("SNERF_X6_TILE") ? atoi(getenv("SNERF_X6_TILE")) : 0;  // diagnostics: 128 | 256
+      // measured in the training step: the 256 x 256 tile wins for the row-contiguous (dW) operands (0.53 vs 0.63 ms),
+      // the 128 x 128 tile with 3 workgroups per CU for the K-contiguous forward / dX launches (0.69 vs 0.73 ms)
+      tile = (forced == 128 || forced == 256) ? forced : (A_IC ? x6_tile(g.I, g.J) : 128);
+    }
+    if (tile == 256) {
+      p.tiles_i = (g.I + 255) / 256; p.tiles_j = (g.J + 255) / 256;
+      grid.x = p.tiles_i * p.tiles_j;
+    }
+    launch_x6(A_IC, g.Bpl != nullptr && !A_IC, g.planes, tile, p, grid, stream);
+  }
   else hipLaunchKernelGGL((gemm_kernel<BI, BJ, WI, WJ, A_IC, B_IC>), grid, dim3(NT), 0, stream, p);
   SNERF_LAUNCH_CHECK();
   if (g_prof_on && rec.a && rec.b) {

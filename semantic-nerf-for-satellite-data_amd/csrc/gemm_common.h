@@ -68,9 +68,9 @@ __device__ __forceinline__ void split_tile_of_block(int x, int z, int tiles, int
 
 // thread -> (row, k) of its r-th float4 in a BI x BK k-tile (element e = t + NT*r of BI*BK/4).
 // KC: BK/4 lanes cover one row's BK floats; IC: BI/4 lanes cover one k-row.
-template <int BI, bool IC>
+template <int BI, bool IC, int NTH = NT>
 __device__ __forceinline__ bool tile_coord(int t, int r, int& il, int& kl) {
-  const int e = t + NT * r;
+  const int e = t + NTH * r;
   if (IC) {
     constexpr int V = BI / 4;
     il = 4 * (e % V);
@@ -86,16 +86,16 @@ __device__ __forceinline__ bool tile_coord(int t, int r, int& il, int& kl) {
 // per-thread loader state of one operand.  Offsets are relative to a per-workgroup descriptor base (the tile's
 // first row for KC operands, the K-split's first k-row for IC operands), so 32-bit offsets never span more than one
 // tile / one split however large the operand is.
-template <int BI, bool IC>
+template <int BI, bool IC, int NTH = NT>
 struct Loader {
-  static constexpr int NV = (BI * BK / 4 + NT - 1) / NT;
+  static constexpr int NV = (BI * BK / 4 + NTH - 1) / NTH;
   unsigned base[NV];  // byte offset of the float4 at the first k of the range, or OOB if its row is outside
   int kl[NV];
   __device__ __forceinline__ void init(int t, int i0, int I, int ld) {
 #pragma unroll
     for (int r = 0; r < NV; ++r) {
       int il, k;
-      const bool in = tile_coord<BI, IC>(t, r, il, k);
+      const bool in = tile_coord<BI, IC, NTH>(t, r, il, k);
       kl[r] = k;
       const unsigned o = IC ? ((unsigned)k * (unsigned)ld + (unsigned)(i0 + il)) * 4u : ((unsigned)il * (unsigned)ld + (unsigned)k) * 4u;
       base[r] = (in && i0 + il < I) ? o : OOB;
@@ -201,6 +201,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
   }
 }
 
-constexpr int epilogue_lds_floats(int WJ) { return 4 * 32 * (WJ + 4); }
+constexpr int epilogue_lds_floats(int WJ, int waves = 4) { return waves * 32 * (WJ + 4); }
 
 }  // namespace snerf

@@ -15,7 +15,24 @@ import os
 from . import _lib
 
 # SNERF_MFMA=fp32 forces the plain fp32 matrix instruction; default is the split-bf16 form (same accuracy class)
-BASE_FLAGS = _lib.FLAG_FP32_MFMA if os.environ.get("SNERF_MFMA", "").lower() == "fp32" else 0
+# SNERF_MFMA=fp32|split3|split2|bf16 overrides every ModelSpec.mfma (diagnostics, bench.py --mfma)
+BASE_FLAGS = _lib.MFMA_FLAGS.get(os.environ.get("SNERF_MFMA", "").lower())
+
+
+def mfma_mode(pipeline_cfg=None, run_cfg=None) -> str:
+    """Matrix-unit arithmetic of the dense layers from the reference's two precision knobs:
+    `precision` (baseline/pipelines/nerf.py:65; 16 = half precision) and the run config's
+    `float32_matmul_precision` (framework/configs.py:26, applied at framework/pipelines.py:254-256).  The build adds
+    the pipeline field `mfma_precision`: "split3" (default: three bf16 planes per fp32 operand, fp32-class results --
+    the 1e-4 parity bar), "fp32" (v_mfma_f32_32x32x2_f32), "split2" (two planes, ~16 significant bits: what
+    torch calls "high"), "bf16" (one plane: "medium" / precision = 16), or "auto" = follow float32_matmul_precision."""
+    mode = getattr(pipeline_cfg, "mfma_precision", "split3")
+    if getattr(pipeline_cfg, "precision", 32) == 16:
+        return "bf16"
+    if mode == "auto":
+        return {"highest": "split3", "high": "split2", "medium": "bf16"}[
+            getattr(run_cfg, "float32_matmul_precision", "highest")]
+    return mode
 
 # parameter names in the reference's state_dict order (SURVEY.md 8(b)) -> SnerfParams field
 _HEAD_FIELDS = {
@@ -50,9 +67,10 @@ class ModelSpec:
     use_tj_for_s: bool = False
     use_separate_beta_for_s: bool = False
     use_separate_tj_for_semantic: bool = False
+    mfma: str = "split3"        # see mfma_mode()
 
     @staticmethod
-    def from_pipeline_cfg(pc, n_classes: int, model: str = "semantic") -> "ModelSpec":
+    def from_pipeline_cfg(pc, n_classes: int, model: str = "semantic", run_cfg=None) -> "ModelSpec":
         sem = model == "semantic"
         W = pc.fc_units
         return ModelSpec(
@@ -64,7 +82,8 @@ class ModelSpec:
             use_tj_instead_of_beta=sem and bool(getattr(pc, "use_tj_instead_of_beta", False)),
             use_tj_for_s=sem and bool(getattr(pc, "use_tj_for_s", False)),
             use_separate_beta_for_s=sem and bool(getattr(pc, "use_separate_beta_for_s", False)),
-            use_separate_tj_for_semantic=sem and bool(getattr(pc, "use_separate_tj_for_semantic", False)))
+            use_separate_tj_for_semantic=sem and bool(getattr(pc, "use_separate_tj_for_semantic", False)),
+            mfma=mfma_mode(pc, run_cfg))
 
     def desc(self, n_rays: int, n_samples: int, flags: int = 0) -> _lib.SnerfDesc:
         mask = 0
@@ -76,7 +95,7 @@ class ModelSpec:
             n_classes=self.n_classes, sem_sigmoid=int(self.sem_sigmoid),
             use_tj_instead_of_beta=int(self.use_tj_instead_of_beta), use_tj_for_s=int(self.use_tj_for_s),
             use_separate_beta_for_s=int(self.use_separate_beta_for_s),
-            use_separate_tj_for_semantic=int(self.use_separate_tj_for_semantic), flags=flags | BASE_FLAGS)
+            use_separate_tj_for_semantic=int(self.use_separate_tj_for_semantic), flags=flags | (_lib.MFMA_FLAGS[self.mfma] if BASE_FLAGS is None else BASE_FLAGS))
 
     def param_names(self) -> list:
         names = []

@@ -45,4 +45,5 @@ class RSSemanticNeRF(_NerfBase):
             self.semantic_beta_from_xyz = torch.nn.Sequential(
                 torch.nn.Linear(tau + self.feat, self.feat_last), nl(), torch.nn.Linear(self.feat_last, 1),
                 torch.nn.Softplus())
-        self.spec = ops.ModelSpec.from_pipeline_cfg(pc, self.semantic_n_classes, model="semantic")
+        self.spec = ops.ModelSpec.from_pipeline_cfg(pc, self.semantic_n_classes, model="semantic",
+                                                    run_cfg=getattr(cfgs, "run", None))

@@ -19,11 +19,14 @@ static double time_gemm(const GemmArgs& g, int reps) {
   return ms / reps;
 }
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IOLBF, 0);
   const bool X6 = argc > 1 && argv[1][0] == 'x';
+  const int PLANES = argc > 2 ? atoi(argv[2]) : 3;
+  const int TILE = argc > 3 ? atoi(argv[3]) : 0;
   const int P = 262144, W = 512;
   float *X, *Wt, *Y, *Y2, *dW, *cs;
   CK(hipMalloc(&X, (size_t)P * W * 4)); CK(hipMalloc(&Wt, (size_t)W * W * 4)); CK(hipMalloc(&Y, (size_t)P * W * 4));
-  CK(hipMalloc(&Y2, (size_t)P * W * 4)); CK(hipMalloc(&dW, (size_t)64 * W * W * 4)); CK(hipMalloc(&cs, (size_t)(P / 32) * W * 4));
+  CK(hipMalloc(&Y2, (size_t)P * W * 4)); CK(hipMalloc(&dW, (size_t)128 * W * W * 4)); CK(hipMalloc(&cs, (size_t)(P / 32) * W * 4));
   std::vector<float> h((size_t)P * W);
   for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u) >> 8 & 0xffff) / 65536.f - 0.5f;
   CK(hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice));
@@ -31,21 +34,24 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(Wt, h.data(), (size_t)W * W * 4, hipMemcpyHostToDevice));
   unsigned short* Bplanes; CK(hipMalloc(&Bplanes, (size_t)3 * W * W * 2 + 4096)); CK(hipMemset(Bplanes, 0, (size_t)3 * W * W * 2));
   const double fl = 2.0 * P * W * W;
-  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6;
+  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
+    time_gemm(g, 400); }  // clock / power state warm-up
+  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
+    if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; }
     double t = time_gemm(g, 20); printf("fwd plain        %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.bias = Wt; g.act = ACT_SIN; g.w0 = 1.f;
     t = time_gemm(g, 20); printf("fwd sin          %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.C2 = Y2;
     t = time_gemm(g, 20); printf("fwd sin+cos out  %.3f ms %.1f TF\n", t, fl / t / 1e9); }
-  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.b_ic = true; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W;
+  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.b_ic = true; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
     double t = time_gemm(g, 20); printf("dX plain         %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.aux = Y2; g.ldaux = W; g.aux_mode = AUX_MUL; g.colsum = cs; g.ldcs = W;
     t = time_gemm(g, 20); printf("dX aux+colsum    %.3f ms %.1f TF\n", t, fl / t / 1e9); }
-  for (int ns : {32, 48, 64}) { GemmArgs g; g.A = X; g.lda = W; g.a_ic = true; g.B = Y2; g.ldb = W; g.b_ic = true; g.I = W; g.J = W; g.K = P; g.C = dW; g.ldc = W; g.x6 = X6;
+  for (int ns : {32, 48, 64, 128}) { GemmArgs g; g.A = X; g.lda = W; g.a_ic = true; g.B = Y2; g.ldb = W; g.b_ic = true; g.I = W; g.J = W; g.K = P; g.C = dW; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
     g.k_split = ((P + ns - 1) / ns + 31) / 32 * 32; g.n_split = (P + g.k_split - 1) / g.k_split; g.slab_stride = (size_t)W * W;
     double t = time_gemm(g, 20); printf("dW split %d      %.3f ms %.1f TF\n", ns, t, fl / t / 1e9); }
   for (int div : {1, 2, 4, 8, 16}) {  // size sweep: fixed per-launch cost?
-    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P / div; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6;
+    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P / div; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
     if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; }
     double t = time_gemm(g, 40); printf("fwd plain I=P/%-2d  %.3f ms %.1f TF\n", div, t, fl / div / t / 1e9);
   }
