@@ -230,6 +230,15 @@ int snerf_loss_partial(const SnerfLossCfg* cfg, const SnerfLossIn* in, float* to
 int snerf_loss_finish(const SnerfLossCfg* cfg, const SnerfLossIn* in, const float* totals, float n_rays_global,
                       float grad_scale, float* terms, const SnerfLossGrads* grads, void* stream);
 
+/* ---- optimiser --------------------------------------------------------------------------------------
+ * One fused Adam step over flat fp32 buffers (parameters, gradients, exp_avg, exp_avg_sq), replacing the reference's
+ * torch.optim.Adam(lr=cfgs.pipeline.learnrate, weight_decay=0) over ~60 tensors
+ * (baseline/pipelines/base_ray_pipeline.py:246-269; StepLR(gamma=0.9) is the caller's `lr`).  `step` counts from 1
+ * (bias corrections 1 - beta^step, computed in double like torch does on the host); gradients are multiplied by
+ * `grad_scale` first (1.0 normally).  n must be a multiple of 4, all buffers 16-byte aligned device memory. */
+int snerf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, unsigned long long n,
+                    float lr, float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+
 /* ---- measurement hook ----------------------------------------------------------------------------
  * Between snerf_profile_begin and snerf_profile_end every GEMM launch is bracketed by HIP events on the
  * stream it is launched on; _end synchronises those events and returns, per kernel variant, the summed

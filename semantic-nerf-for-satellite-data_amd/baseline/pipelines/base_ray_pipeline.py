@@ -45,7 +45,10 @@ class BaseRayPipeline(Pipeline):
         return {"loss": loss}
 
     def configure_optimizers(self):
+        # same optimiser and schedule as the reference (:246-269), as ONE fused HIP launch over a flat parameter
+        # buffer whose flat gradient twin doubles as the all-reduce bucket (optim.py)
+        from ...optim import FlatAdam, StepLR
         params = [p for m in self.models.values() for p in m.parameters()]
-        self.optimizer = torch.optim.Adam(params, lr=self.cfgs.pipeline.learnrate, weight_decay=0)
-        scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=1, gamma=0.9)
+        self.optimizer = FlatAdam(params, lr=self.cfgs.pipeline.learnrate, weight_decay=0)
+        scheduler = StepLR(self.optimizer, step_size=1, gamma=0.9)
         return {"optimizer": self.optimizer, "lr_scheduler": {"scheduler": scheduler, "interval": "epoch"}}

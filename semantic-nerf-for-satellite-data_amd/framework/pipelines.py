@@ -129,14 +129,40 @@ class TrainLoop:
         batch = {"rgb": self.bank.batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)}
         if "depth" in pl.datasets:
             batch["depth"] = pl.datasets["depth"].batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)
-        self.optimizer.zero_grad(set_to_none=True)
+        self.optimizer.zero_grad()
         out = pl.training_step(batch, step)
         out["loss"].backward()
-        self.bucket = parallel.allreduce_gradients(self.params, self.bucket)
+        if hasattr(self.optimizer, "flat_g"):
+            # every .grad is a view of the optimiser's flat gradient buffer: it is the all-reduce bucket
+            self.optimizer._collect_foreign_grads()
+            self.bucket = parallel.allreduce_sum_(self.optimizer.flat_g)
+        else:
+            self.bucket = parallel.allreduce_gradients(self.params, self.bucket)
         self.optimizer.step()
         if (step + 1) % self.steps_per_epoch == 0:
             self.scheduler.step()
         return out
+
+
+    # ---- checkpoints (Lightning layout; framework/util/load_ckpoint.py) ----------------------------------------
+    def save_ckpoint(self, checkpoint_fp):
+        from .util.load_ckpoint import save_ckpoint
+        return save_ckpoint(self.pipeline, checkpoint_fp, self.optimizer, self.scheduler,
+                            epoch=self.pipeline.train_steps // self.steps_per_epoch, global_step=self.pipeline.train_steps)
+
+    def load_ckpoint(self, checkpoint_fp):
+        """Resume: weights, Adam moments + step count, StepLR epoch, train_steps (trainer.fit(ckpt_path=...),
+        framework/pipelines.py:321-331)."""
+        from .util import load_ckpoint as lc
+        ck = lc._safe_load(checkpoint_fp, self.device)
+        for key, m in self.pipeline.models.items():
+            lc.load_ckpoint(m, checkpoint_fp, f"model_{key}", self.device)
+        if ck.get("optimizer_states"):
+            self.optimizer.load_state_dict(ck["optimizer_states"][0])
+        if ck.get("lr_schedulers"):
+            self.scheduler.load_state_dict(ck["lr_schedulers"][0])
+        self.pipeline.train_steps = int(ck.get("global_step", 0))
+        return self.pipeline.train_steps
 
 
 def run_pipeline(pipeline, cfgs, device=None, max_steps=None, on_step=None):

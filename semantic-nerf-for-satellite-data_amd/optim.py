@@ -1,0 +1,150 @@
+"""Optimiser of the ray pipelines: Adam(lr, weight_decay=0) + StepLR(step_size=1, gamma=0.9) per epoch
+(baseline/pipelines/base_ray_pipeline.py:246-269), re-laid for the GPU:
+
+* every parameter is a view into ONE flat fp32 buffer, every .grad a view into ONE flat gradient buffer -- the
+  gradient buffer IS the RCCL all-reduce bucket (no gather / scatter copies) and zero_grad is one memset;
+* the update is ONE HIP launch (snerf_adam_step) instead of torch's multi-tensor sequence over ~60 tensors;
+* state_dict() / load_state_dict() speak torch.optim.Adam's format, so optimizer_states of a Lightning-style
+  checkpoint written by the reference resume here and vice versa (framework/util/load_ckpoint.py).
+"""
+import ctypes as C
+from typing import Iterable, List
+
+import torch
+
+from . import _lib
+
+
+def _round4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class FlatAdam:
+    """torch.optim.Adam surface (param_groups, step, zero_grad, state_dict) over flat buffers."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdam: no trainable parameters")
+        if weight_decay != 0:
+            raise ValueError("FlatAdam: the reference runs Adam with weight_decay=0 (base_ray_pipeline.py:262)")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdam: parameters must live on the GPU -- the HIP path has no CPU fallback")
+        for p in self.params:
+            if p.device != dev or p.dtype != torch.float32:
+                raise ValueError("FlatAdam: all parameters must be fp32 on one device")
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += _round4(p.numel())       # every view 16-byte aligned
+        self.numel = off
+        self.flat_p = torch.zeros(off, device=dev)
+        self.flat_g = torch.zeros(off, device=dev)
+        self.exp_avg = torch.zeros(off, device=dev)
+        self.exp_avg_sq = torch.zeros(off, device=dev)
+        self._gviews = []
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                v = self.flat_p[o:o + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                g = self.flat_g[o:o + p.numel()].view_as(p)
+                p.grad = g
+                self._gviews.append(g)
+        self.step_count = 0
+        self.param_groups = [{"lr": float(lr), "betas": tuple(betas), "eps": float(eps), "weight_decay": 0.0,
+                              "amsgrad": False, "params": list(range(len(self.params)))}]
+
+    # ---- torch.optim surface ------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False):
+        """One memset of the flat gradient buffer; the .grad views stay attached (autograd accumulates in place)."""
+        self.flat_g.zero_()
+        for p, g in zip(self.params, self._gviews):
+            if p.grad is not g:
+                p.grad = g
+
+    def _collect_foreign_grads(self):
+        # a .grad that autograd (or user code) replaced by a fresh tensor: fold it into the flat buffer
+        for p, g in zip(self.params, self._gviews):
+            if p.grad is None:
+                continue
+            if p.grad is not g and p.grad.data_ptr() != g.data_ptr():
+                g.copy_(p.grad)
+                p.grad = g
+
+    @torch.no_grad()
+    def step(self, grad_scale: float = 1.0):
+        self._collect_foreign_grads()
+        self.step_count += 1
+        grp = self.param_groups[0]
+        L = _lib.lib()
+        st = torch.cuda.current_stream(self.flat_p.device).cuda_stream
+        _lib.check(L.snerf_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                     self.exp_avg_sq.data_ptr(), C.c_ulonglong(self.numel), grp["lr"], grp["betas"][0],
+                                     grp["betas"][1], grp["eps"], self.step_count, float(grad_scale), C.c_void_p(st)),
+                   "snerf_adam_step")
+
+    def state_dict(self):
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
+        groups = [dict(g, betas=tuple(g["betas"])) for g in self.param_groups]
+        return {"state": state if self.step_count > 0 else {}, "param_groups": groups}
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        n_saved = sum(len(g["params"]) for g in groups)
+        if n_saved != len(self.params):
+            raise ValueError(f"FlatAdam: checkpoint holds {n_saved} parameters, the pipeline has {len(self.params)}")
+        g0 = groups[0]
+        self.param_groups[0].update(lr=float(g0["lr"]), betas=tuple(g0["betas"]), eps=float(g0["eps"]))
+        steps = set()
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            s = sd["state"].get(i)
+            if s is None:
+                continue
+            n = p.numel()
+            if tuple(s["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FlatAdam: state {i} has shape {tuple(s['exp_avg'].shape)}, parameter {tuple(p.shape)}")
+            self.exp_avg[o:o + n].view_as(p).copy_(s["exp_avg"])
+            self.exp_avg_sq[o:o + n].view_as(p).copy_(s["exp_avg_sq"])
+            steps.add(int(float(s["step"])))
+        if len(steps) > 1:
+            raise ValueError("FlatAdam: per-parameter step counts differ; one shared count is supported")
+        self.step_count = steps.pop() if steps else 0
+
+
+class StepLR:
+    """torch.optim.lr_scheduler.StepLR(optimizer, step_size, gamma): lr = base_lr * gamma ** (epoch // step_size);
+    the pipelines step it once per epoch (base_ray_pipeline.py:264-268)."""
+
+    def __init__(self, optimizer, step_size: int = 1, gamma: float = 0.9):
+        self.optimizer, self.step_size, self.gamma = optimizer, int(step_size), float(gamma)
+        self.base_lrs = [g["lr"] for g in optimizer.param_groups]
+        self.last_epoch = 0
+
+    def _apply(self):
+        for g, b in zip(self.optimizer.param_groups, self.base_lrs):
+            g["lr"] = b * self.gamma ** (self.last_epoch // self.step_size)
+
+    def step(self):
+        self.last_epoch += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [g["lr"] for g in self.optimizer.param_groups]
+
+    def state_dict(self):
+        return {"step_size": self.step_size, "gamma": self.gamma, "base_lrs": list(self.base_lrs),
+                "last_epoch": self.last_epoch, "_last_lr": self.get_last_lr()}
+
+    def load_state_dict(self, sd):
+        self.step_size, self.gamma = int(sd["step_size"]), float(sd["gamma"])
+        self.base_lrs, self.last_epoch = list(sd["base_lrs"]), int(sd["last_epoch"])
+        self._apply()

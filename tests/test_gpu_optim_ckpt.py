@@ -1,0 +1,129 @@
+"""Fused HIP Adam (snerf_adam_step behind optim.FlatAdam) and Lightning-layout checkpoints -- SURVEY 8(f) rank 3."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import snerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def test_fused_adam_matches_torch_adam():
+    """5 steps of the one-launch Adam on ragged parameter shapes == torch.optim.Adam (CPU, fp32) to fp32 rounding;
+    the exchanged state_dicts load into each other."""
+    from snerf_amd.optim import FlatAdam, StepLR
+    g = torch.Generator().manual_seed(3)
+    shapes = [(7, 5), (33,), (128, 63), (1,), (2, 3, 5)]
+    ref_p = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    hip_p = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=5e-4, weight_decay=0)
+    ref_s = torch.optim.lr_scheduler.StepLR(ref, step_size=1, gamma=0.9)
+    hip = FlatAdam(hip_p, lr=5e-4, weight_decay=0)
+    hip_s = StepLR(hip, step_size=1, gamma=0.9)
+    for it in range(5):
+        ref.zero_grad()
+        hip.zero_grad()
+        for a, b in zip(ref_p, hip_p):
+            gr = torch.randn(a.shape, generator=g) * (10.0 ** (it - 3))
+            a.grad = gr.clone()
+            b.grad.add_(gr.to(DEV))          # accumulate in place into the flat view, as autograd does
+        ref.step()
+        hip.step()
+        if it % 2 == 1:
+            ref_s.step()
+            hip_s.step()
+        assert abs(ref.param_groups[0]["lr"] - hip.param_groups[0]["lr"]) < 1e-12
+    for a, b in zip(ref_p, hip_p):
+        assert torch.allclose(a.detach(), b.detach().cpu(), rtol=2e-6, atol=1e-7), float((a.detach() - b.detach().cpu()).abs().max())
+    # a gradient tensor that replaced the view (p.grad = fresh tensor) is folded in on step()
+    hip.zero_grad(); ref.zero_grad()
+    for a, b in zip(ref_p, hip_p):
+        gr = torch.randn(a.shape, generator=g)
+        a.grad = gr.clone(); b.grad = gr.to(DEV)
+    ref.step(); hip.step()
+    for a, b in zip(ref_p, hip_p):
+        assert torch.allclose(a.detach(), b.detach().cpu(), rtol=2e-6, atol=1e-7)
+    # state_dict interop, both directions
+    sd = hip.state_dict()
+    ref2 = torch.optim.Adam([torch.nn.Parameter(p.detach().cpu().clone()) for p in hip_p], lr=1.0)
+    ref2.load_state_dict(sd)
+    assert abs(ref2.param_groups[0]["lr"] - hip.param_groups[0]["lr"]) < 1e-12
+    assert int(ref2.state_dict()["state"][0]["step"]) == 6
+    hip2 = FlatAdam([torch.nn.Parameter(p.detach().clone()) for p in hip_p], lr=1.0)
+    hip2.load_state_dict(ref.state_dict())
+    assert hip2.step_count == 6
+    for i, p in enumerate(ref_p):
+        o = hip2.offsets[i]
+        assert torch.allclose(hip2.exp_avg[o:o + p.numel()].cpu(), ref.state_dict()["state"][i]["exp_avg"].reshape(-1))
+
+
+def test_fused_adam_refuses_bad_arguments():
+    from snerf_amd import _lib
+    from snerf_amd.optim import FlatAdam
+    with pytest.raises(RuntimeError):
+        FlatAdam([torch.nn.Parameter(torch.zeros(4))])          # CPU parameters: no fallback
+    with pytest.raises(ValueError):
+        FlatAdam([torch.nn.Parameter(torch.zeros(4, device=DEV))], weight_decay=0.1)
+    L = _lib.lib()
+    t = torch.zeros(8, device=DEV)
+    assert L.snerf_adam_step(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 6, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) != 0
+    assert L.snerf_adam_step(t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 8, 1e-3, 0.9, 0.999, 1e-8, 0, 1.0, None) != 0
+    assert L.snerf_adam_step(None, t.data_ptr(), t.data_ptr(), t.data_ptr(), 8, 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None) != 0
+
+
+def _loop(seed=4, max_steps=100):
+    from tests.test_gpu_pipeline import _pipeline_for
+    from snerf_amd.framework.pipelines import TrainLoop
+    cfg = O.OracleCfg(fc_units=32, n_samples=16, first_beta_epoch=0)
+    pipe, _ = _pipeline_for(cfg, 64, seed, max_steps=max_steps)
+    pipe.log_metrics = False
+    return TrainLoop(pipe, pipe.cfgs, DEV)
+
+
+def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
+    """train 3 steps, save (Lightning layout), resume in a fresh pipeline: steps 4-5 give the same losses and
+    weights as the uninterrupted run; the file reads with torch.load(weights_only=True)."""
+    from snerf_amd.framework.util import load_ckpoint as lc
+    a = _loop()
+    for s in range(3):
+        torch.manual_seed(100 + s)
+        a.step(s)
+    fp = a.save_ckpoint(str(tmp_path / "run" / "ckpoints" / "epoch=0.ckpt"))
+    ck = torch.load(fp, weights_only=True)
+    assert ck["global_step"] == 3 and set(ck) >= {"epoch", "global_step", "state_dict", "optimizer_states", "lr_schedulers"}
+    assert all(k.split(".")[0] in ("model_coarse", "model_t") for k in ck["state_dict"])
+    assert lc.find_ckpoint_fp(str(tmp_path / "run"), -1) == (fp, 0)
+    assert lc.read_ckpt_info(fp) == (0, 3)
+    cont = []
+    for s in range(3, 5):
+        torch.manual_seed(100 + s)
+        cont.append(float(a.step(s)["loss"]))
+    b = _loop(seed=9)                       # different initial weights: everything must come from the file
+    assert b.load_ckpoint(fp) == 3
+    res = []
+    for s in range(3, 5):
+        torch.manual_seed(100 + s)
+        res.append(float(b.step(s)["loss"]))
+    assert np.allclose(cont, res, rtol=0, atol=1e-6), (cont, res)
+    for (n, p), (_, q) in zip(a.pipeline.named_parameters(), b.pipeline.named_parameters()):
+        assert torch.allclose(p, q, rtol=0, atol=1e-7), n
+    # evaluation-side loading (load_from_disk) and prefix filters
+    models, pipe, epoch, dev = lc.load_from_disk(b.cfgs, str(tmp_path / "run"), epoch=0, device=0)
+    assert epoch == 0 and not models["coarse"].training
+    sd = lc.extract_model_state_dict(fp, "model_coarse", "cpu", prefixes_to_ignore=["fc_net"])
+    assert sd and not any(k.startswith("fc_net") for k in sd)
+    only = lc.extract_model_state_dict(fp, "model_coarse", "cpu", prefixes_to_load=["fc_net"])
+    assert only and all(k.startswith("fc_net") for k in only)
+
+
+def test_trainloop_gradients_live_in_the_flat_bucket():
+    loop = _loop()
+    torch.manual_seed(0)
+    loop.step(0)
+    opt = loop.optimizer
+    assert all(p.grad.data_ptr() == g.data_ptr() for p, g in zip(opt.params, opt._gviews))
+    assert all(p.data_ptr() == opt.flat_p.data_ptr() + 4 * o for p, o in zip(opt.params, opt.offsets))
+    assert float(opt.flat_g.abs().sum()) > 0 and opt.step_count == 1

@@ -130,3 +130,36 @@ def test_model_forward_is_fused_only():
     m = SatNeRF(types.SimpleNamespace(pipeline=pc), feat=32, t_embedding_dims=4)
     with pytest.raises(NotImplementedError):
         m(torch.zeros(4, 3))
+
+
+def test_checkpoint_utilities_cpu(tmp_path):
+    """Lightning-layout reader (framework/util/load_ckpoint.py): model-prefix extraction, epoch lookup, and the
+    safe-loader rule -- a checkpoint that needs unpickling of arbitrary objects is refused, never executed."""
+    import torch
+    from snerf_amd.framework.util import load_ckpoint as lc
+    d = tmp_path / "logs" / "ckpoints"
+    d.mkdir(parents=True)
+    sd = {"model_coarse.fc_net.0.weight": torch.ones(2, 3), "model_coarse.sigma_from_xyz.0.bias": torch.zeros(1),
+          "model_t.weight": torch.full((4, 2), 2.0)}
+    for ep in (0, 3, 12):
+        torch.save({"epoch": ep, "global_step": 10 * ep, "state_dict": sd}, d / f"epoch={ep}.ckpt")
+    fp, ep = lc.find_ckpoint_fp(str(tmp_path / "logs"), -1)
+    assert ep == 12 and fp.endswith("epoch=12.ckpt")
+    assert lc.find_ckpoint_fp(str(tmp_path / "logs"), 3)[0].endswith("epoch=3.ckpt")
+    assert lc.read_ckpt_info(fp) == (12, 120)
+    got = lc.extract_model_state_dict(fp, "model_coarse")
+    assert sorted(got) == ["fc_net.0.weight", "sigma_from_xyz.0.bias"]
+    assert list(lc.extract_model_state_dict(fp, "model_t")) == ["weight"]
+    assert list(lc.extract_model_state_dict(fp, "model_coarse", prefixes_to_ignore=["fc_net"])) == ["sigma_from_xyz.0.bias"]
+    m = torch.nn.Module()
+    m.weight = torch.nn.Parameter(torch.zeros(4, 2))
+    assert lc.load_ckpoint(m, fp, "model_t") == [] and float(m.weight.sum()) == 16.0
+    m.weight = torch.nn.Parameter(torch.zeros(5, 2))
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        lc.load_ckpoint(m, fp, "model_t")
+
+    # any object a pickle would have to instantiate (here: a non-allow-listed class) makes the safe loader refuse
+    import fractions
+    torch.save({"epoch": 0, "global_step": 0, "state_dict": sd, "hyper_parameters": fractions.Fraction(1, 3)}, d / "last.ckpt")
+    with pytest.raises(RuntimeError, match="weights_only"):
+        lc.read_ckpt_info(str(d / "last.ckpt"))
