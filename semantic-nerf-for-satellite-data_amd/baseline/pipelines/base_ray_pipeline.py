@@ -49,6 +49,10 @@ class BaseRayPipeline(Pipeline):
         # buffer whose flat gradient twin doubles as the all-reduce bucket (optim.py)
         from ...optim import FlatAdam, StepLR
         params = [p for m in self.models.values() for p in m.parameters()]
+        import os
+        if os.environ.get("SNERF_TORCH_ADAM") == "1":  # diagnostics only: stock multi-tensor Adam for A/B timing
+            self.optimizer = torch.optim.Adam(params, lr=self.cfgs.pipeline.learnrate, weight_decay=0)
+            return {"optimizer": self.optimizer, "lr_scheduler": {"scheduler": torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=1, gamma=0.9), "interval": "epoch"}}
         self.optimizer = FlatAdam(params, lr=self.cfgs.pipeline.learnrate, weight_decay=0)
         scheduler = StepLR(self.optimizer, step_size=1, gamma=0.9)
         return {"optimizer": self.optimizer, "lr_scheduler": {"scheduler": scheduler, "interval": "epoch"}}

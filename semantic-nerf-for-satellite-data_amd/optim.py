@@ -58,21 +58,33 @@ class FlatAdam:
                               "amsgrad": False, "params": list(range(len(self.params)))}]
 
     # ---- torch.optim surface ------------------------------------------------------------------------------
-    def zero_grad(self, set_to_none: bool = False):
-        """One memset of the flat gradient buffer; the .grad views stay attached (autograd accumulates in place)."""
+    def zero_grad(self, set_to_none: bool = True):
+        """set_to_none (default, as torch): drop the .grad references -- autograd then hands over each pass's gradient
+        tensors without an add kernel per parameter, and step() gathers them into the flat buffer with one
+        multi-tensor copy.  set_to_none=False: one memset, .grad stays a view of the flat buffer and autograd
+        accumulates into it in place."""
+        if set_to_none:
+            for p in self.params:
+                p.grad = None
+            return
         self.flat_g.zero_()
         for p, g in zip(self.params, self._gviews):
             if p.grad is not g:
                 p.grad = g
 
     def _collect_foreign_grads(self):
-        # a .grad that autograd (or user code) replaced by a fresh tensor: fold it into the flat buffer
+        """Make flat_g hold every gradient: .grad tensors that are not views of it are gathered by one multi-tensor
+        copy (and re-pointed at their view); parameters without a gradient contribute zeros."""
+        src, dst = [], []
         for p, g in zip(self.params, self._gviews):
             if p.grad is None:
-                continue
-            if p.grad is not g and p.grad.data_ptr() != g.data_ptr():
-                g.copy_(p.grad)
-                p.grad = g
+                g.zero_()
+            elif p.grad.data_ptr() != g.data_ptr():
+                src.append(p.grad.detach())
+                dst.append(g)
+            p.grad = g
+        if src:
+            torch._foreach_copy_(dst, src)
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):

@@ -25,7 +25,7 @@ def test_fused_adam_matches_torch_adam():
     hip_s = StepLR(hip, step_size=1, gamma=0.9)
     for it in range(5):
         ref.zero_grad()
-        hip.zero_grad()
+        hip.zero_grad(set_to_none=False)   # in-place mode: .grad stays a view of the flat bucket
         for a, b in zip(ref_p, hip_p):
             gr = torch.randn(a.shape, generator=g) * (10.0 ** (it - 3))
             a.grad = gr.clone()
