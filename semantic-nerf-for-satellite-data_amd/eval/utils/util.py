@@ -18,3 +18,46 @@ def batched_inference(cfgs, renderer, models, rays, extras, render_options={}, e
         for k, v in r.items():
             parts[k].append(v)
     return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in parts.items()}
+
+
+_KEY_SHAPES = {  # per-ray trailing shape of the render_rays results (S = n_samples, C = classes)
+    "rgb": lambda S, C: (3,), "depth": lambda S, C: (), "weights": lambda S, C: (S,), "transparency": lambda S, C: (S,),
+    "albedo": lambda S, C: (S, 3), "sun": lambda S, C: (S, 1), "sky": lambda S, C: (S, 3), "beta": lambda S, C: (S, 1),
+    "sigmas": lambda S, C: (S,), "beta_semantic": lambda S, C: (S, 1), "semantic_logits": lambda S, C: (C,),
+    "semantic_label": lambda S, C: (), "weights_sc": lambda S, C: (S,), "transparency_sc": lambda S, C: (S,),
+    "sun_sc": lambda S, C: (S, 1),
+}
+
+
+@torch.no_grad()
+def lean_inference(cfgs, renderer, models, rays, extras, keys=("rgb_coarse", "depth_coarse", "semantic_label_coarse"),
+                   render_options={}, show_tqdm=False):
+    """Full-frame inference for image / point-cloud extraction (eval/extract_pointcloud.py:66-79 calls
+    batched_inference and then reads only rgb and depth): the full-frame result tensors are allocated once, every
+    chunk of render_chunk_size rays writes its rows in place, only the requested results are produced (no per-sample
+    tensors unless asked for), the solar-correction pass is skipped unless one of its results is requested, and the
+    weights are packed once for all chunks."""
+    from ... import ops
+    chunk = cfgs.pipeline.render_chunk_size
+    n = rays.shape[0]
+    S = cfgs.pipeline.n_samples
+    model = models["coarse"]
+    Cn = model.spec.n_classes
+    out = {}
+    for k in keys:
+        bare = k[:-len("_coarse")] if k.endswith("_coarse") else k
+        if bare not in _KEY_SHAPES:
+            raise KeyError(f"lean_inference: unknown result '{k}'")
+        dt = torch.int64 if bare == "semantic_label" else torch.float32
+        out[bare + "_coarse"] = torch.empty((n,) + _KEY_SHAPES[bare](S, Cn), dtype=dt, device=rays.device)
+    opts = dict(render_options) if render_options else {}
+    opts["packed_params"] = ops.pack_params(model.spec, dict(model.named_parameters()))
+    steps = range(0, n, chunk)
+    if show_tqdm:
+        from tqdm import tqdm
+        steps = tqdm(steps)
+    for i in steps:
+        sl = {k: v[i:i + chunk] for k, v in out.items()}
+        opts["workspace"] = renderer.render_rays_into(models, rays[i:i + chunk],
+                                                       extras[i:i + chunk] if extras is not None else None, sl, opts)
+    return out

@@ -39,6 +39,22 @@ class BaseRenderer:
         # "_coarse" postfix as in the reference (no fine network is ever built)
         return {f"{k}_coarse": v for k, v in model_results.items()}
 
+    @torch.no_grad()
+    def render_rays_into(self, models: dict, rays: torch.Tensor, extras: torch.Tensor, out: dict, render_options={}):
+        """Inference-only render_rays that fills the preallocated tensors of `out` (keys as render_rays returns them,
+        e.g. 'rgb_coarse', 'depth_coarse', 'semantic_label_coarse') and computes nothing else.  Returns the pass's
+        workspace buffer so that a caller can hand it back through render_options['workspace'] for the next chunk."""
+        from ...semantic.components.rendering import fused_model_rendering_into
+        opts = dict(render_options) if render_options else {}
+        if "perturb_rand" not in opts and opts.get("perturb", 1.0) > 0:
+            opts["perturb_rand"] = torch.rand(rays.shape[0], self.N_samples, device=rays.device, dtype=torch.float32)
+        bare = {}
+        for k, v in out.items():
+            if not k.endswith("_coarse"):
+                raise KeyError(f"render_rays_into: result keys end in '_coarse', got '{k}'")
+            bare[k[:-len("_coarse")]] = v
+        return fused_model_rendering_into(self, models, "coarse", rays, extras, opts, bare)
+
     @abc.abstractmethod
     def _model_rendering(self, models: dict, typ: str, cfgs, rays, extras, xyz, z_vals, rays_d, epoch=None,
                          progress=1.0, render_options=None) -> dict:

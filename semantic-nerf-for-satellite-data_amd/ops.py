@@ -320,6 +320,51 @@ def render_pass(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Tensor,
     return out
 
 
+@torch.no_grad()
+def render_pass_into(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Tensor, t_s: torch.Tensor | None,
+                     out: dict, sc_pass: bool = False, packed: torch.Tensor | None = None,
+                     workspace: torch.Tensor | None = None) -> torch.Tensor:
+    """Inference-only pass that produces ONLY the result tensors named in `out` and writes them in place:
+    `out` maps result keys (output_keys(), 'semantic_label', 'z_vals') to preallocated contiguous tensors of the
+    pass's shapes -- typically row slices of full-frame buffers, so a chunked render never concatenates
+    (eval/utils/util.py:13-42 re-concatenates every key per chunk).  Every other SnerfOutputs pointer stays NULL and
+    the composite kernel skips it.  Returns the workspace (pass it back in for the next chunk of the same size)."""
+    L = _lib.lib()
+    N = t.shape[0]
+    S = (pin.z_vals.shape[1] if pin.z_vals is not None else
+         (pin.u.shape[1] if pin.u is not None else pin.z_steps.shape[0]))
+    dev = t.device
+    d = spec.desc(N, S, _lib.FLAG_SC_PASS if sc_pass else 0)
+    nbytes = L.snerf_workspace_bytes(C.byref(d))
+    if nbytes == 0:
+        _lib.check(1, "snerf_workspace_bytes")
+    if workspace is None or workspace.numel() < nbytes or workspace.device != dev:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    allowed = set(output_keys(spec, sc_pass)) | {"z_vals"} | ({"semantic_label"} if spec.n_classes > 0 and not sc_pass else set())
+    so = _lib.SnerfOutputs()
+    for k, v in out.items():
+        if k not in allowed:
+            raise KeyError(f"render_pass_into: '{k}' is not a result of this pass (have {sorted(allowed)})")
+        if not v.is_cuda:
+            raise RuntimeError(f"snerf_amd: out['{k}'] must live on the GPU (the HIP path has no CPU fallback)")
+        want = (N,) if k == "semantic_label" else ((N, S) if k == "z_vals" else _OUT_SHAPES[k](N, S, spec.n_classes))
+        if tuple(v.shape) != tuple(want) or not v.is_contiguous():
+            raise ValueError(f"render_pass_into: out['{k}'] must be a contiguous {tuple(want)} tensor, got {tuple(v.shape)}")
+        if v.dtype != (torch.int64 if k == "semantic_label" else torch.float32):
+            raise ValueError(f"render_pass_into: out['{k}'] has dtype {v.dtype}")
+        setattr(so, k, v.data_ptr())
+    if packed is None:
+        packed = pack_params(spec, params)
+    _check_dev(t, "t")
+    tc = t.contiguous()
+    tsc = t_s.contiguous() if t_s is not None else None
+    si = pin.struct(tc, tsc)
+    with torch.cuda.device(dev):
+        _lib.check(L.snerf_forward(C.byref(d), _ptr(packed), C.byref(si), C.byref(so), _ptr(workspace), workspace.numel(),
+                                   _stream()), "snerf_forward")
+    return workspace
+
+
 def sample_z(rays: torch.Tensor, z_steps: torch.Tensor, u: torch.Tensor | None) -> torch.Tensor:
     """stratified depths (N,S) -- snerf_sample_z"""
     L = _lib.lib()

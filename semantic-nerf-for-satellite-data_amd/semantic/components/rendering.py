@@ -78,6 +78,40 @@ def fused_model_rendering(renderer, models, typ, rays, extras, render_options, i
     return result
 
 
+_SC_KEYS = {"weights_sc": "weights", "transparency_sc": "transparency", "sun_sc": "sun"}
+
+
+@torch.no_grad()
+def fused_model_rendering_into(renderer, models, typ, rays, extras, render_options, out: dict):
+    """Inference-only twin of fused_model_rendering: writes just the results named in `out` (un-suffixed keys) into
+    the given tensors.  The solar-correction pass runs only if one of its three results is asked for -- a point-cloud
+    or image render (rgb / depth / label) does half the work of render_rays."""
+    opts = render_options or {}
+    sun_d = extras_component_fn(extras, "sun_d")
+    ts = extras_component_fn(extras, "ts").squeeze(-1).long()
+    rays_t = models["t"](ts)
+    rays_t_s = models["t_s"](ts) if "t_s" in models else None
+    model = models[typ]
+    params = dict(model.named_parameters())
+    packed = opts.get("packed_params")
+    if packed is None:
+        packed = ops.pack_params(model.spec, params)
+    main_out = {k: v for k, v in out.items() if k not in _SC_KEYS}
+    sc_out = {_SC_KEYS[k]: v for k, v in out.items() if k in _SC_KEYS}
+    ws = opts.get("workspace")
+    z = opts.get("given_z_vals")
+    if sc_out and z is None:   # both passes must share the depths
+        z = ops.sample_z(rays, z_steps_on(rays.device, renderer.N_samples), opts.get("perturb_rand"))
+    pin = ops.PassInputs(sun_d=sun_d, rays=rays, z_vals=z, z_steps=z_steps_on(rays.device, renderer.N_samples),
+                         u=opts.get("perturb_rand"))
+    if main_out:
+        ws = ops.render_pass_into(model.spec, params, pin, rays_t, rays_t_s, main_out, packed=packed, workspace=ws)
+    if sc_out:
+        ws = ops.render_pass_into(model.spec, params, ops.PassInputs(sun_d=sun_d, rays=rays, z_vals=z), rays_t, rays_t_s,
+                                  sc_out, sc_pass=True, packed=packed, workspace=ws)
+    return ws
+
+
 class RSSemanticRendering(BaseRenderer):
     def __init__(self, cfgs, inference=rs_semantic_inference):
         super().__init__(cfgs)

@@ -299,3 +299,36 @@ def test_full_frame_inference_chunk_beyond_4gib():
     assert torch.equal(big["semantic_label_coarse"][idx], small["semantic_label_coarse"])
     del big
     torch.cuda.empty_cache()
+
+
+def test_lean_inference_equals_batched_inference(tmp_path):
+    """lean_inference (requested results only, written in place per chunk, sc pass only on request) returns the same
+    values as the reference-shaped batched_inference; extract_pointcloud's xyz is o + d*depth in double."""
+    from snerf_amd.eval.utils.util import batched_inference, lean_inference
+    from snerf_amd.eval.extract_pointcloud import extract_pointcloud, filtered_indices, save_ply
+    cfg = O.OracleCfg(fc_units=64, n_samples=16)
+    pipe, _ = _pipeline_for(cfg, 64, 3, render_chunk_size=100)
+    b = O.batch_to_torch(O.synthetic_batch(333, 16, seed=8))        # 4 chunks, ragged tail
+    rays, extras = b["rays"].to(DEV), b["extras"].to(DEV)
+    ro = {"perturb": 0}
+    full = batched_inference(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, render_options=ro)
+    keys = ("rgb_coarse", "depth_coarse", "semantic_label_coarse", "weights_coarse", "sun_sc_coarse", "beta_coarse")
+    lean = lean_inference(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, keys=keys, render_options=ro)
+    assert sorted(lean) == sorted(keys)
+    for k in keys:
+        assert lean[k].shape == full[k].shape, k
+        assert torch.equal(lean[k], full[k]), (k, float((lean[k].float() - full[k].float()).abs().max()))
+    only = lean_inference(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, render_options=ro)
+    assert sorted(only) == ["depth_coarse", "rgb_coarse", "semantic_label_coarse"]
+    with pytest.raises(KeyError):
+        lean_inference(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, keys=("rgb_fine",))
+    pc = extract_pointcloud(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, render_options=ro)
+    assert pc["xyz_n"].dtype == torch.float64 and pc["xyz_n"].shape == (333, 3)
+    want = rays[:, :3].double() + rays[:, 3:6].double() * full["depth_coarse"].double().view(-1, 1)
+    assert torch.equal(pc["xyz_n"], want) and torch.equal(pc["labels"], full["semantic_label_coarse"])
+    idx = filtered_indices(333, keep=50)
+    assert len(idx) == 50 and torch.equal(idx, filtered_indices(333, keep=50))
+    fp = save_ply(str(tmp_path / "cloud.ply"), pc["xyz_n"][idx.to(DEV)], pc["colors"][idx.to(DEV)], pc["labels"][idx.to(DEV)])
+    raw = open(fp, "rb").read()
+    head, body = raw.split(b"end_header\n")
+    assert b"element vertex 50" in head and len(body) == 50 * (24 + 3 + 1)
