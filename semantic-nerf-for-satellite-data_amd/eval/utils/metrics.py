@@ -1,10 +1,15 @@
-"""PSNR -- mirror of eval/utils/metrics.py:8-18 (logging metric)."""
+"""MSE / PSNR -- mirror of eval/utils/metrics.py:8-18 (device reductions; SSIM stays with the CPU tooling)."""
 import torch
 
 
-def mse(image_pred, image_gt):
-    return torch.mean((image_pred - image_gt) ** 2)
+def mse(image_pred, image_gt, valid_mask=None, reduction="mean"):
+    value = (image_pred - image_gt) ** 2
+    if valid_mask is not None:
+        value = value[valid_mask]
+    if reduction == "mean":
+        return torch.mean(value)
+    return value
 
 
-def psnr(image_pred, image_gt):
-    return -10 * torch.log10(mse(image_pred, image_gt))
+def psnr(image_pred, image_gt, valid_mask=None, reduction="mean"):
+    return -10 * torch.log10(mse(image_pred, image_gt, valid_mask, reduction))

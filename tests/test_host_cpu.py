@@ -163,3 +163,45 @@ def test_checkpoint_utilities_cpu(tmp_path):
     torch.save({"epoch": 0, "global_step": 0, "state_dict": sd, "hyper_parameters": fractions.Fraction(1, 3)}, d / "last.ckpt")
     with pytest.raises(RuntimeError, match="weights_only"):
         lc.read_ckpt_info(str(d / "last.ckpt"))
+
+
+def test_validation_metrics_match_reference_definitions():
+    """semantic_error / accuracy (filter_idx rows count as right, denominator = all rays), row-normalised confusion
+    matrix, mIoU with nanmean over absent classes, beta-at-transient, masked PSNR -- against plain numpy restatements
+    of semantic/components/metrics.py:11-87 and eval/utils/metrics.py:8-18."""
+    import numpy as np
+    import torch
+    from snerf_amd.semantic.components import metrics as M
+    from snerf_amd.eval.utils.metrics import mse, psnr
+    rng = np.random.default_rng(5)
+    N, S, Cn = 500, 8, 6                       # class 5 never occurs: NaN IoU -> skipped
+    gt = rng.integers(0, 5, size=(N, 1)).astype(np.uint8)
+    pred = np.where(rng.random(N) < 0.7, gt[:, 0], rng.integers(0, 5, size=N)).astype(np.int64)
+    res = {"semantic_label_coarse": torch.from_numpy(pred), "rgb_coarse": torch.zeros(N, 3),
+           "weights_coarse": torch.from_numpy(rng.random((N, S)).astype(np.float32)),
+           "beta_coarse": torch.from_numpy(rng.random((N, S, 1)).astype(np.float32))}
+    tg = torch.from_numpy(gt)
+    err = (gt[:, 0] != pred).astype(np.float32)
+    assert abs(float(M.semantic_accuracy(res, tg)) - (1 - err.sum() / N)) < 1e-6
+    err4 = np.where(gt[:, 0] == 4, 0.0, err)
+    assert abs(float(M.semantic_accuracy(res, tg, filter_idx=4)) - (1 - err4.sum() / N)) < 1e-6
+    assert M.semantic_error(res["semantic_label_coarse"], tg).shape == tg.shape
+    counts = np.zeros((Cn, Cn))
+    for g, p in zip(gt[:, 0], pred):
+        counts[g, p] += 1
+    cm_counts = M.confusion_matrix_values(res, tg, Cn, normalize=None).numpy()
+    assert np.array_equal(cm_counts, counts)
+    cm = M.confusion_matrix_values(res, tg, Cn).numpy()
+    rows = counts.sum(1, keepdims=True)
+    assert np.allclose(cm, np.divide(counts, rows, out=np.zeros_like(counts), where=rows > 0), atol=1e-6)
+    ious = np.array([counts[c, c] / (counts[c].sum() + counts[:, c].sum() - counts[c, c]) if
+                     (counts[c].sum() + counts[:, c].sum()) > 0 else np.nan for c in range(Cn)])
+    assert abs(float(M.semantic_mIoU(cm_counts)) - np.nanmean(ious)) < 1e-9
+    w, b = res["weights_coarse"].numpy(), res["beta_coarse"].numpy()
+    comp = (w[..., None] * b).sum(-2)[:, 0]
+    car = gt[:, 0] == 3
+    assert abs(float(M.uncertainty_at_transient(res, tg, 3)) - comp[car].sum() / car.sum()) < 1e-5
+    a, c = torch.rand(40, 3), torch.rand(40, 3)
+    mask = torch.rand(40) > 0.5
+    assert abs(float(psnr(a, c, mask)) - float(-10 * torch.log10(((a - c) ** 2)[mask].mean()))) < 1e-6
+    assert mse(a, c, reduction="none").shape == (40, 3)
