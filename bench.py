@@ -118,7 +118,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-GEMM HIP-event timing")
     ap.add_argument("--serial-passes", action="store_true", help="run main and sc pass on one stream (as the roofline phase does)")
-    ap.add_argument("--mfma", default="split3", choices=["split3", "fp32", "split2", "bf16"],
+    ap.add_argument("--mfma", default="split3", choices=["split3", "fp32", "split2", "bf16", "split3_bwd2"],
                     help="matrix arithmetic: split3 = fp32-class (headline, default); split2 / bf16 are the REDUCED-precision "
                          "modes of BASELINE configs[2]/[4] (reported under their own dtype, never as the fp32 headline)")
     ap.add_argument("--eager-gpu-baseline", action="store_true", help="also time the oracle with stock PyTorch ops on the GPU")
@@ -200,7 +200,8 @@ def main():
         "scaling": "weak", "vs_baseline": None,
         "dtype": {"split3": "f32 (fp32 storage and accumulate; products on bf16 MFMA via 3-plane splits, fp32-level accuracy)",
                   "fp32": "f32", "split2": "REDUCED: f32 storage/accumulate, operands as 2 bf16 planes (~16 bits, torch 'high')",
-                  "bf16": "REDUCED: bf16 operands, f32 accumulate and storage (torch 'medium' / precision=16)"}[mode],
+                  "bf16": "REDUCED: bf16 operands, f32 accumulate and storage (torch 'medium' / precision=16)",
+                  "split3_bwd2": "f32 forward (3-plane splits, fp32-level results); REDUCED backward: 2 bf16 planes (~16 bits) in dX / dW"}[mode],
         "data": "synthetic",
         "config": {"workload": "JAX_068 semantic pipeline (configs[1]): RSSemanticNeRF fc_units=512 x 8 layers, C=5, "
                                f"{args.rays} rays x {args.samples} samples per GPU, fp32, main + solar-correction pass, "
@@ -219,7 +220,7 @@ def main():
         fam_ms = sum(prof.ms[v] for v in range(3)); fam_fl = sum(prof.flops[v] for v in range(3))
         # split-bf16 kernel: the contraction at this accuracy IS six bf16 MFMA products per fp32 product, so the
         # kernel's algorithmic work is 6 x (2 I J K) bf16 flops, priced against the dense bf16 MFMA peak
-        mult, peak = ({"split3": 6.0, "split2": 3.0, "bf16": 1.0}[mode], BF16_MFMA_PEAK_TFLOPS) if x6 else (1.0, FP32_MFMA_PEAK_TFLOPS)
+        mult, peak = ({"split3": 6.0, "split2": 3.0, "bf16": 1.0, "split3_bwd2": 4.0}[mode], BF16_MFMA_PEAK_TFLOPS) if x6 else (1.0, FP32_MFMA_PEAK_TFLOPS)
         achieved = fp32_eq * mult
         # HBM bytes per launch of that kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
         # the MI355X guide), measured on this exact workload: profiles/r01/pmc_hbm_traffic.md

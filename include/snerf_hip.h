@@ -54,6 +54,10 @@ extern "C" {
                                   Judged on PSNR / mIoU, not on the 1e-4 parity bar. */
 #define SNERF_FLAG_BF16X3 16u  /* REDUCED precision: two bf16 planes (hi | mid), products hh + hm + mh: ~16 significant bits */
 
+#define SNERF_FLAG_BWD_BF16X3 32u /* REDUCED precision in snerf_backward only: forward results keep the default fp32-class
+                                   arithmetic (the 1e-4 output bar), the dX / dW contractions use two planes (gradients
+                                   ~1e-4 relative) */
+
 /* Model + batch description.  Field names follow the reference config
  * (configs/pipelines/rs_semantic.toml:13-67, semantic/pipelines/rs_semantic.py:125-141). */
 typedef struct SnerfDesc {

@@ -12,7 +12,8 @@ FLAG_FP32_MFMA = 4  # contract on v_mfma_f32_32x32x2_f32 instead of the default 
 FLAG_BF16 = 8       # reduced precision: one bf16 plane per operand (precision = 16 / float32_matmul_precision "medium")
 FLAG_BF16X3 = 16    # reduced precision: two bf16 planes, three products (float32_matmul_precision "high")
 # ModelSpec.mfma -> SnerfDesc.flags
-MFMA_FLAGS = {"split3": 0, "fp32": FLAG_FP32_MFMA, "split2": FLAG_BF16X3, "bf16": FLAG_BF16}
+FLAG_BWD_BF16X3 = 32  # reduced precision (two planes) in the backward contractions only
+MFMA_FLAGS = {"split3": 0, "fp32": FLAG_FP32_MFMA, "split2": FLAG_BF16X3, "bf16": FLAG_BF16, "split3_bwd2": FLAG_BWD_BF16X3}
 
 _fp = C.POINTER(C.c_float)
 

@@ -595,6 +595,7 @@ int snerf_backward(const SnerfDesc* desc, const float* packed_params, const Sner
   if (((uintptr_t)workspace & 255) || ((uintptr_t)packed_params & 255) || ((uintptr_t)packed_grads & 255)) { set_error("workspace and packed buffers must be 256-byte aligned"); return SNERF_ERR_WORKSPACE; }
   RC(check_inputs(p, in));
   WS ws{(char*)workspace};
+  if ((desc->flags & SNERF_FLAG_BWD_BF16X3) && p.x6 && p.planes == 3) p.planes = 2;  // same Plan, fewer products in backward
   return backward_impl(p, packed_params, in, gout, packed_grads, d_t, d_t_s, ws, (hipStream_t)stream);
 }
 

@@ -296,8 +296,10 @@ def test_reduced_precision_modes_full_width(monkeypatch):
     pn = fixture_params(z, meta, cfg)
     b = fixture_batch(z)
     grads = {}
+    outs = {}
     for name, flags, out_tol, loss_tol in (("split3", 0, OUT_TOL, 2e-4), ("split2", _lib.FLAG_BF16X3, 1e-4, 2e-4),
-                                           ("bf16", _lib.FLAG_BF16, 2e-2, 1e-2)):
+                                           ("bf16", _lib.FLAG_BF16, 2e-2, 1e-2),
+                                           ("split3_bwd2", _lib.FLAG_BWD_BF16X3, OUT_TOL, 2e-4)):
         monkeypatch.setattr(ops, "BASE_FLAGS", flags)
         gp = _gpu_params(pn, dev, requires_grad=True)
         emb_g = torch.from_numpy(O.init_embedding_numpy(cfg, meta["seed"])).to(dev).requires_grad_(True)
@@ -313,6 +315,10 @@ def test_reduced_precision_modes_full_width(monkeypatch):
             assert abs(float(ld[k].detach()) - ref) <= loss_tol * max(1.0, abs(ref)), (name, k)
         O.total_loss(ld).backward()
         grads[name] = {k: v.grad.clone().cpu() for k, v in gp.items()}
+        outs[name] = {k: v.detach().cpu() for k, v in hip.items()}
+    # backward-only reduction: the forward is the default one bit for bit, the gradients are the two-plane ones
+    assert all(torch.equal(outs["split3_bwd2"][k], outs["split3"][k]) for k in outs["split3"])
+    assert max(float(rel_err(grads["split3_bwd2"][k], grads["split3"][k])) for k in grads["split3"]) <= 1e-3
     worst2 = max(float(rel_err(grads["split2"][k], grads["split3"][k])) for k in grads["split3"])
     assert worst2 <= 1e-3, worst2
     assert all(torch.isfinite(g).all() for g in grads["bf16"].values())
