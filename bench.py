@@ -214,7 +214,7 @@ def main():
     step_tflops = flops_step_gpu * args.steps / dt / 1e12  # per GPU, algorithmic (SURVEY 8d figure)
     if prof is not None:
         x6 = mode != "fp32"
-        # dominant kernel = variant 0: gemm_x6_kernel<false,true> (forward X.W^T and dX), ~62 % of device time
+        # dominant kernel = variant 0: gemm_x6_kernel<false,true,3,128> (forward X.W^T and dX), ~64 % of device time
         ms, fl, n = prof.ms[0], prof.flops[0], prof.launches[0]
         fp32_eq = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         fam_ms = sum(prof.ms[v] for v in range(3)); fam_fl = sum(prof.flops[v] for v in range(3))
@@ -224,10 +224,10 @@ def main():
         achieved = fp32_eq * mult
         # HBM bytes per launch of that kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
         # the MI355X guide), measured on this exact workload: profiles/r01/pmc_hbm_traffic.md
-        traffic = 1.684e9 if (mode == "split3" and args.rays == 4096 and args.samples == 64) else None
+        traffic = 1.694e9 if (mode == "split3" and args.rays == 4096 and args.samples == 64) else None
         line["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "kernel": ("snerf::gemm_x6_kernel<false,true> (split-bf16: 3 bf16 planes per fp32 operand, 6 x v_mfma_f32_32x32x16_bf16 per "
+            "kernel": ("snerf::gemm_x6_kernel<false,true,NP,128> (split-bf16: NP = 3 bf16 planes per fp32 operand, 6 x v_mfma_f32_32x32x16_bf16 per "
                        "32x32x16 block, fp32 accumulate; forward X.W^T and dX launches)" if x6 else
                        "snerf::gemm_kernel<128,128,64,64,false,false> (v_mfma_f32_32x32x2_f32)"),
             "fp32_equivalent_tflops": fp32_eq, "vs_fp32_mfma_peak": fp32_eq / FP32_MFMA_PEAK_TFLOPS,
