@@ -116,18 +116,21 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.o_rgbraw = wtake((size_t)p.N * 3);
   p.o_pe = wtake(Pp * p.Ep);
   const bool keep_c = p.train && p.siren;
+  static const bool float_deriv = getenv("SNERF_DERIV") && !strcmp(getenv("SNERF_DERIV"), "float");  // diagnostics: A/B
+  p.sign_deriv = !float_deriv;
+  auto dsize = [&](int ld) { return p.sign_deriv ? sign_floats(Pp, ld) : Pp * (size_t)ld; };
   if (p.train) {
     for (int i = 0; i < p.L; ++i) p.o_h[i] = wtake(Pp * p.W);
-    for (int i = 0; i < p.L; ++i) p.o_c[i] = keep_c ? wtake(Pp * p.W) : 0;
+    for (int i = 0; i < p.L; ++i) p.o_c[i] = keep_c ? wtake(dsize(p.W)) : 0;  // sign words of cos, 1 bit / element
   } else {
     const size_t a = wtake(Pp * p.W), b = wtake(Pp * p.W);
     for (int i = 0; i < p.L; ++i) { p.o_h[i] = (i & 1) ? b : a; p.o_c[i] = 0; }
   }
   p.o_fa = wtake(Pp * p.FA);
   p.o_h1 = wtake(Pp * p.h1w);
-  p.o_c1 = keep_c ? wtake(Pp * p.h1w) : 0;
+  p.o_c1 = keep_c ? wtake(dsize(p.h1w)) : 0;
   p.o_s2 = wtake(Pp * p.H); p.o_s3 = wtake(Pp * p.H);
-  p.o_cs2 = keep_c ? wtake(Pp * p.H) : 0; p.o_cs3 = keep_c ? wtake(Pp * p.H) : 0;
+  p.o_cs2 = keep_c ? wtake(dsize(p.H)) : 0; p.o_cs3 = keep_c ? wtake(dsize(p.H)) : 0;
   p.o_sigo = wtake(Pp * NARROW); p.o_fino = wtake(Pp * NARROW); p.o_suno = wtake(Pp * NARROW);
   p.maxw = p.W > p.FA ? p.W : p.FA;
   if (p.h1w > p.maxw) p.maxw = p.h1w;
@@ -231,6 +234,7 @@ static void build_tables(const Plan& p, const SnerfParams* w, TableBuilder& tb) 
 struct WS {
   char* base;
   float* f(size_t off) const { return reinterpret_cast<float*>(base + off); }
+  unsigned* u(size_t off) const { return reinterpret_cast<unsigned*>(base + off); }
 };
 
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
@@ -277,7 +281,7 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
     g.I = P; g.J = W; g.K = p.k_tr[i];
     g.C = ws.f(p.o_h[i]); g.ldc = W;
     g.bias = pk + p.b_tr[i]; g.act = act; g.w0 = (p.siren && i == 0) ? 30.f : 1.f;
-    g.C2 = (p.train && p.siren) ? ws.f(p.o_c[i]) : nullptr;
+    if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_c[i]); else g.C2 = ws.f(p.o_c[i]); }
     RC(launch_gemm(g, st));
   }
   const float* hl = ws.f(p.o_h[p.L - 1]);
@@ -299,7 +303,7 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
     const size_t r0 = p.sc ? (size_t)p.blk_sun * H : 0;
     weights(g, p, pk, p.w_h1, p.N1, p.FA, (int)r0); g.J = p.h1w;
     g.C = ws.f(p.o_h1); g.ldc = p.h1w; g.bias = pk + p.b_h1 + r0; g.act = act; g.w0 = 1.f;
-    g.C2 = (p.train && p.siren) ? ws.f(p.o_c1) : nullptr;
+    if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_c1); else g.C2 = ws.f(p.o_c1); }
     RC(launch_gemm(g, st));
   }
   const int sun_col = p.sc ? 0 : p.blk_sun * H;
@@ -307,10 +311,10 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
     GemmArgs g;
     g.A = ws.f(p.o_h1) + sun_col; g.lda = p.h1w; weights(g, p, pk, p.w_s2, H, H); g.I = P; g.J = H; g.K = H;
     g.C = ws.f(p.o_s2); g.ldc = H; g.bias = pk + p.b_s2; g.act = act;
-    g.C2 = (p.train && p.siren) ? ws.f(p.o_cs2) : nullptr;
+    if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_cs2); else g.C2 = ws.f(p.o_cs2); }
     RC(launch_gemm(g, st));
     g.A = ws.f(p.o_s2); g.lda = H; weights(g, p, pk, p.w_s3, H, H); g.bias = pk + p.b_s3; g.C = ws.f(p.o_s3);
-    g.C2 = (p.train && p.siren) ? ws.f(p.o_cs3) : nullptr;
+    if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_cs3); else g.C2 = ws.f(p.o_cs3); }
     RC(launch_gemm(g, st));
   }
   {  // sun visibility output pre-activation
@@ -376,9 +380,15 @@ static int bias_from_narrow(const Plan& p, WS ws, const float* dnar, float* gout
 static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutGrads* go, float* gp,
                          float* d_t, float* d_t_s, WS ws, hipStream_t st) {
   const int P = p.P, W = p.W, H = p.H;
-  const int aux_mode = p.siren ? AUX_MUL : AUX_RELU_MASK;
-  // activation-derivative source for a buffer: saved w0*cos (siren) or the activation itself (relu mask)
-  auto dact = [&](size_t o_c, size_t o_h) { return p.siren ? ws.f(o_c) : ws.f(o_h); };
+  // activation derivative applied in a dX epilogue.  siren: w0 * sign(cos) * sqrt(1 - h^2) from the stored activation
+  // h = sin(w0 z) (buffer o_h, leading dimension ld, column col0) and the sign words the forward launch wrote (o_c);
+  // relu: mask by h > 0.
+  auto dact = [&](GemmArgs& g, size_t o_c, size_t o_h, int ld, int col0 = 0, float w0 = 1.f) {
+    g.aux = ws.f(o_h) + col0; g.ldaux = ld;
+    if (p.siren && p.sign_deriv) { g.aux_mode = AUX_SINREC; g.aux_sign = ws.u(o_c); g.sign_col0 = col0; g.w0 = w0; }
+    else if (p.siren) { g.aux = ws.f(o_c) + col0; g.aux_mode = AUX_MUL; }
+    else g.aux_mode = AUX_RELU_MASK;
+  };
   float* dsig = ws.f(p.o_dsig); float* dfin = ws.f(p.o_dfin); float* dsun = ws.f(p.o_dsun);
   // 0. composite backward -> gradients of the NARROW-wide pre-activations (+ sky MLP grads)
   CompBwdArgs b;
@@ -406,7 +416,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(bias_from_narrow(p, ws, dfin, gp + p.b_fin, st));
     GemmArgs g;  // dz1[:, :KF] = (dfin . W_fin) * act'
     g.A = dfin; g.lda = NARROW; weights(g, p, pk, p.t_fin, p.KF, NARROW); g.I = P; g.J = p.KF; g.K = NARROW;
-    g.C = dz1; g.ldc = p.h1w; g.aux = dact(p.o_c1, p.o_h1); g.ldaux = p.h1w; g.aux_mode = aux_mode;
+    g.C = dz1; g.ldc = p.h1w; dact(g, p.o_c1, p.o_h1, p.h1w);
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));
     RC(bias_from_colsum(p, ws, p.KF, gp + p.b_h1, st));
@@ -419,20 +429,20 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(bias_from_narrow(p, ws, dsun, gp + p.b_s4, st));
     GemmArgs g;
     g.A = dsun; g.lda = NARROW; weights(g, p, pk, p.t_s4, H, NARROW); g.I = P; g.J = H; g.K = NARROW;
-    g.C = ws.f(p.o_dsa); g.ldc = H; g.aux = dact(p.o_cs3, p.o_s3); g.ldaux = H; g.aux_mode = aux_mode;
+    g.C = ws.f(p.o_dsa); g.ldc = H; dact(g, p.o_cs3, p.o_s3, H);
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));  // dz_s3
     RC(bias_from_colsum(p, ws, H, gp + p.b_s3, st));
     RC(dw_gemm(p, ws, mh, ws.f(p.o_dsa), H, H, false, ws.f(p.o_s2), H, H, 0, st));
     RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s3, st));
     g.A = ws.f(p.o_dsa); g.lda = H; weights(g, p, pk, p.t_s3, H, H); g.K = H;
-    g.C = ws.f(p.o_dsb); g.aux = dact(p.o_cs2, p.o_s2);
+    g.C = ws.f(p.o_dsb); dact(g, p.o_cs2, p.o_s2, H);
     RC(launch_gemm(g, st));  // dz_s2
     RC(bias_from_colsum(p, ws, H, gp + p.b_s2, st));
     RC(dw_gemm(p, ws, mh, ws.f(p.o_dsb), H, H, false, ws.f(p.o_h1) + sun_col, p.h1w, H, 0, st));
     RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s2, st));
     g.A = ws.f(p.o_dsb); weights(g, p, pk, p.t_s2, H, H);
-    g.C = dz1 + sun_col; g.ldc = p.h1w; g.aux = dact(p.o_c1, p.o_h1) + sun_col; g.ldaux = p.h1w;
+    g.C = dz1 + sun_col; g.ldc = p.h1w; dact(g, p.o_c1, p.o_h1, p.h1w, sun_col);
     RC(launch_gemm(g, st));  // dz1[:, sun block]
     RC(bias_from_colsum(p, ws, H, gp + p.b_h1 + (size_t)p.blk_sun * H, st));
   }
@@ -462,7 +472,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     GemmArgs g;
     g.A = dfa; g.lda = p.FA; g.Ka = W; g.A2 = dsig; g.lda2 = NARROW;
     weights(g, p, pk, p.t_fs, W, W + NARROW); g.I = P; g.J = W; g.K = W + NARROW;
-    g.C = dz; g.ldc = W; g.aux = dact(p.o_c[p.L - 1], p.o_h[p.L - 1]); g.ldaux = W; g.aux_mode = aux_mode;
+    g.C = dz; g.ldc = W; dact(g, p.o_c[p.L - 1], p.o_h[p.L - 1], W, 0, (p.L == 1) ? 30.f : 1.f);
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));
     RC(bias_from_colsum(p, ws, W, gp + p.b_tr[p.L - 1], st));
@@ -481,7 +491,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     GemmArgs g;
     g.A = dz_cur; g.lda = W; weights(g, p, pk, p.t_tr[i], W, W);
     g.I = P; g.J = W; g.K = W; g.C = dz_nxt; g.ldc = W;
-    g.aux = dact(p.o_c[i - 1], p.o_h[i - 1]); g.ldaux = W; g.aux_mode = aux_mode;
+    dact(g, p.o_c[i - 1], p.o_h[i - 1], W, 0, (i - 1 == 0) ? 30.f : 1.f);
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));
     RC(bias_from_colsum(p, ws, W, gp + p.b_tr[i - 1], st));

@@ -7,7 +7,7 @@
 namespace snerf {
 
 enum GemmAct { ACT_NONE = 0, ACT_SIN = 1, ACT_RELU = 2 };
-enum GemmAux { AUX_NONE = 0, AUX_MUL = 1, AUX_RELU_MASK = 2 };
+enum GemmAux { AUX_NONE = 0, AUX_MUL = 1, AUX_RELU_MASK = 2, AUX_SINREC = 3 };
 
 // C[i, j] = epilogue( sum_k A(i,k) * B(j,k) )
 // Operand storage: "KC" (k-contiguous): element (i,k) at P[i*ld + k]; "IC" (i-contiguous): P[k*ld + i].
@@ -25,9 +25,17 @@ struct GemmArgs {
   int act = ACT_NONE;
   float w0 = 1.f;
   float* C2 = nullptr;
+  // C2s (optional, instead of C2): ONE SIGN BIT of cos(w0*z) per element -- all the backward pass needs besides the
+  // stored activation h = sin(w0*z): w0*cos = w0 * sign * sqrt(1 - h^2).  32x less derivative traffic than C2.
+  // Layout: per 32-row block and 64-column group 64 words; word rrow*16 + (col/4)%16 holds, for rows rrow + 4*ps
+  // (ps = 0..7) and the 4 columns of one epilogue lane, bit 4*ps + c.  sign_floats() gives the buffer size.
+  unsigned* C2s = nullptr;
   // backward epilogue: multiply by aux (saved activation derivative) or mask by aux > 0 (ReLU);
   // colsum (optional): per-32-row partial column sums of the final values, [ceil(I/32)][ldcs] (bias grads)
   const float* aux = nullptr; int ldaux = 0; int aux_mode = AUX_NONE;
+  // AUX_SINREC: aux = the stored activation h (same shape as C), aux_sign = the sign words written through C2s by the
+  // forward launch, sign_col0 = column of aux inside its buffer (a multiple of 4); multiplies by w0*sign*sqrt(1-h^2)
+  const unsigned* aux_sign = nullptr; int sign_col0 = 0;
   float* colsum = nullptr; int ldcs = 0;
   // split-K (dW): blockIdx.z = split s handles k in [s*k_split, (s+1)*k_split), writes C + s*slab_stride
   int k_split = 0; int n_split = 1; size_t slab_stride = 0;
@@ -42,6 +50,9 @@ struct GemmArgs {
   int planes = 3;         // bf16 planes per operand of the split kernel: 3 fp32-class, 2 ~16-bit, 1 plain bf16
   bool x6 = false;        // split-bf16 MFMA (gemm_x6.hip) for the 128x128 tile when both operands share a layout
 };
+
+// floats of a sign-word buffer covering `rows` (a multiple of 32) x `ld` elements (GemmArgs::C2s)
+inline size_t sign_floats(size_t rows, int ld) { return rows / 32 * (size_t)((ld + 63) / 64) * 64; }
 
 // tile of the split kernel for an I x J problem: 256 x 256 when that covers no more padded area than 128 x 128
 inline int x6_tile(int I, int J) {

@@ -240,6 +240,8 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
   KArgs p;
   p.A = g.A; p.A2 = g.A2 ? g.A2 : g.A; p.B = g.B; p.C = g.C; p.C2 = g.C2;
   p.bias = g.bias; p.aux = g.aux; p.colsum = g.colsum;
+  p.C2s = g.C2s; p.auxs = g.aux_sign; p.sign_col0 = g.aux_sign ? g.sign_col0 : 0;
+  p.sign_groups = ((g.aux_sign ? g.ldaux : g.ldc) + 63) / 64;
   p.lda = g.lda; p.lda2 = g.A2 ? g.lda2 : g.lda; p.Ka = g.A2 ? g.Ka : 0x7fffffff;
   p.ldb = g.ldb; p.I = g.I; p.J = g.J; p.K = g.K; p.ldc = g.ldc; p.ldaux = g.ldaux; p.ldcs = g.ldcs;
   // operand extents for the buffer descriptors (bytes; checked < 4 GiB by launch_gemm)
@@ -330,6 +332,8 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
   if (g.Bpl && ((g.bt_k0 & 15) || ((uintptr_t)g.Bpl & 15) || (g.pl_stride & 7) || g.bt_rows <= 0 || g.pl_stride * 6 >= 0xFFFFFFF0ull))
     return bad("pre-split B planes need bt_k0 % 16 == 0 and 16-byte alignment");
   if (g.aux && g.aux_mode != AUX_NONE && g.ldaux <= 0) return bad("aux needs ldaux");
+  if (g.C2s && (g.narrow_j || g.act != ACT_SIN || g.aux_sign)) return bad("C2s (sign words) needs the 64-wide epilogue, ACT_SIN and no AUX_SINREC");
+  if (g.aux_mode == AUX_SINREC && (!g.aux || !g.aux_sign || g.narrow_j || (g.sign_col0 & 3))) return bad("AUX_SINREC needs aux, aux_sign, sign_col0 % 4 == 0 and the 64-wide epilogue");
 
   if (!g.a_ic && !g.b_ic) {
     if (g.narrow_j) return launch_cfg<128, 32, 32, 32, false, false>(g, stream);

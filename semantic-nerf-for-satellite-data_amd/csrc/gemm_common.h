@@ -25,6 +25,7 @@ struct KArgs {
   const float* A; const float* A2; const float* B;
   float* C; float* C2;
   const float* bias; const float* aux; float* colsum;
+  unsigned* C2s; const unsigned* auxs; int sign_col0, sign_groups;
   unsigned bytesA, bytesA2, bytesB;
   const unsigned short* Bpl; unsigned pl_stride_bytes; unsigned bytesBpl; int bt_rows, bt_row0, bt_k0;
   int lda, lda2, Ka, ldb, I, J, K, ldc, ldaux, ldcs;
@@ -154,6 +155,14 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
         for (int r = 0; r < 16; ++r)
           strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + 32 * nj + lc] = acc[mi][nj][r];
       float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+      // sign words of the activation derivative (see GemmArgs::C2s): one word per lane and 32-row block
+      unsigned sbits = 0u, sword = 0u;
+      size_t sidx = 0;
+      if (WJ == 64 && (p.C2s != nullptr || p.aux_mode == AUX_SINREC)) {
+        const int cabs = col + p.sign_col0;
+        sidx = ((size_t)(rbase >> 5) * p.sign_groups + (cabs >> 6)) * 64 + rrow * 16 + ((cabs >> 2) & 15);
+        if (p.aux_mode == AUX_SINREC && col_ok) sword = p.auxs[sidx];
+      }
 #pragma unroll
       for (int ps = 0; ps < 32 / RPP; ++ps) {
         const int rl = rrow + RPP * ps;
@@ -168,6 +177,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
           sincos_acc(p.w0 * v.y, &v.y, &cn.y);
           sincos_acc(p.w0 * v.z, &v.z, &cn.z);
           sincos_acc(p.w0 * v.w, &v.w, &cn.w);
+          if (WJ == 64 && p.C2s != nullptr)
+            sbits |= ((cn.x < 0.f ? 1u : 0u) | (cn.y < 0.f ? 2u : 0u) | (cn.z < 0.f ? 4u : 0u) | (cn.w < 0.f ? 8u : 0u)) << (4 * ps);
           if (p.C2 != nullptr && ok) {
             cn.x *= p.w0; cn.y *= p.w0; cn.z *= p.w0; cn.w *= p.w0;
             *reinterpret_cast<float4*>(p.C2 + off) = cn;
@@ -179,6 +190,14 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
           float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
           if (ok) x = *reinterpret_cast<const float4*>(p.aux + (size_t)row * p.ldaux + col);
           if (p.aux_mode == AUX_MUL) { v.x *= x.x; v.y *= x.y; v.z *= x.z; v.w *= x.w; }
+          else if (p.aux_mode == AUX_SINREC) {
+            // x = h = sin(w0 z): |cos| = sqrt(1 - h^2) (one rounding: fma), sign from the stored bit
+            const unsigned nib = sword >> (4 * ps);
+            const float dx = p.w0 * sqrtf(fmaxf(fmaf(-x.x, x.x, 1.f), 0.f)), dy = p.w0 * sqrtf(fmaxf(fmaf(-x.y, x.y, 1.f), 0.f));
+            const float dz = p.w0 * sqrtf(fmaxf(fmaf(-x.z, x.z, 1.f), 0.f)), dw = p.w0 * sqrtf(fmaxf(fmaf(-x.w, x.w, 1.f), 0.f));
+            v.x *= (nib & 1u) ? -dx : dx; v.y *= (nib & 2u) ? -dy : dy;
+            v.z *= (nib & 4u) ? -dz : dz; v.w *= (nib & 8u) ? -dw : dw;
+          }
           else { v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f; }
         }
         if (ok) {
@@ -186,6 +205,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
           cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
         }
       }
+      if (WJ == 64 && p.C2s != nullptr && col_ok) p.C2s[sidx] = sbits;
 #ifndef SNERF_ABL_CLOCK
       if (p.colsum != nullptr) {
         // rows of this 32-row block live on lanes with equal (lane % LPR): butterfly over the row bits

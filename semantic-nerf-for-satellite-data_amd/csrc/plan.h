@@ -46,6 +46,7 @@ struct Plan {
   size_t t_fin = 0;  // [KF][NARROW]
   size_t n_fp32 = 0;         // floats of the fp32 region (parameters + transposes); bf16 planes follow it
   size_t packed_floats = 0;  // whole packed buffer in floats: fp32 region + 3 bf16 planes of it
+  bool sign_deriv = true;  // SIREN derivative kept as sign bits + recomputed from h (false: stored w0*cos floats)
   int planes = 3;    // bf16 planes per operand: 3 (default, fp32-class), 2 (SNERF_FLAG_BF16X3), 1 (SNERF_FLAG_BF16)
   bool x6 = true;    // split-bf16 MFMA for the 128x128 GEMMs (fp32 MFMA when SNERF_FLAG_FP32_MFMA)
 
