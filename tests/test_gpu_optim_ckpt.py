@@ -127,3 +127,44 @@ def test_trainloop_gradients_live_in_the_flat_bucket():
     assert all(p.grad.data_ptr() == g.data_ptr() for p, g in zip(opt.params, opt._gviews))
     assert all(p.data_ptr() == opt.flat_p.data_ptr() + 4 * o for p, o in zip(opt.params, opt.offsets))
     assert float(opt.flat_g.abs().sum()) > 0 and opt.step_count == 1
+
+
+_LOOP_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from snerf_amd import parallel
+rank, world, dev = parallel.init_distributed(backend="gloo")
+from tests.test_gpu_optim_ckpt import _loop
+torch.rand = lambda *a, **k: torch.zeros(*a, device=k.get("device"), dtype=k.get("dtype", torch.float32))
+loop = _loop()
+assert (loop.rank, loop.world) == (rank, 2)
+losses = [float(loop.step(s)["loss"].detach()) for s in range(3)]
+if rank == 0:
+    torch.save({{"losses": losses, "params": {{n: p.detach().cpu() for n, p in loop.pipeline.named_parameters()}}}}, {out!r})
+dist.barrier()
+"""
+
+
+def test_trainloop_two_ranks_equal_one_rank(tmp_path, monkeypatch):
+    """TrainLoop on 2 ranks (gloo, both on this GPU; each renders its half of every global batch, the flat gradient
+    bucket is all-reduced, FlatAdam steps) == TrainLoop on 1 rank with the whole batch, after 3 optimiser steps."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    monkeypatch.setattr(torch, "rand", lambda *a, **k: torch.zeros(*a, device=k.get("device"), dtype=k.get("dtype", torch.float32)))
+    one = _loop()
+    ref_losses = [float(one.step(s)["loss"].detach()) for s in range(3)]
+    ref = {n: p.detach().cpu() for n, p in one.pipeline.named_parameters()}
+    monkeypatch.undo()
+    res = str(tmp_path / "loop.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(_LOOP_WORKER.format(root=root, out=res))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"), cwd=root) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    two = torch.load(res, weights_only=True)
+    # the reported loss is the rank-local one (its own rays, global denominators); weights must agree
+    for n, v in ref.items():
+        assert torch.allclose(two["params"][n], v, rtol=0, atol=2e-5), (n, float((two["params"][n] - v).abs().max()))
+    assert all(np.isfinite(two["losses"])) and all(np.isfinite(ref_losses))
