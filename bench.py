@@ -34,7 +34,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "P
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
-def make_cfgs(rays_per_gpu, samples, world, mfma="split3"):
+def make_cfgs(rays_per_gpu, samples, world, mfma="f16x2"):
     from snerf_amd.framework.configs import MainConfig
     pipeline = {
         "pipeline": "snerf_amd.semantic.pipelines.rs_semantic.RSSemanticPipeline",
@@ -118,8 +118,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-GEMM HIP-event timing")
     ap.add_argument("--serial-passes", action="store_true", help="run main and sc pass on one stream (as the roofline phase does)")
-    ap.add_argument("--mfma", default="split3", choices=["split3", "fp32", "split2", "bf16", "split3_bwd2"],
-                    help="matrix arithmetic: split3 = fp32-class (headline, default); split2 / bf16 are the REDUCED-precision "
+    ap.add_argument("--mfma", default="f16x2", choices=["split3", "f16x2", "fp32", "split2", "bf16", "split3_bwd2"],
+                    help="matrix arithmetic: f16x2 (default, headline) and split3 are fp32-class; split2 / split3_bwd2 / bf16 are the REDUCED-precision "
                          "modes of BASELINE configs[2]/[4] (reported under their own dtype, never as the fp32 headline)")
     ap.add_argument("--eager-gpu-baseline", action="store_true", help="also time the oracle with stock PyTorch ops on the GPU")
     args = ap.parse_args()
@@ -199,6 +199,7 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
         "dtype": {"split3": "f32 (fp32 storage and accumulate; products on bf16 MFMA via 3-plane splits, fp32-level accuracy)",
+                  "f16x2": "f32 (fp32 storage and accumulate; products on fp16 MFMA via 2-plane splits of power-of-two-scaled operands, fp32-level accuracy)",
                   "fp32": "f32", "split2": "REDUCED: f32 storage/accumulate, operands as 2 bf16 planes (~16 bits, torch 'high')",
                   "bf16": "REDUCED: bf16 operands, f32 accumulate and storage (torch 'medium' / precision=16)",
                   "split3_bwd2": "f32 forward (3-plane splits, fp32-level results); REDUCED backward: 2 bf16 planes (~16 bits) in dX / dW"}[mode],
@@ -218,17 +219,20 @@ def main():
         ms, fl, n = prof.ms[0], prof.flops[0], prof.launches[0]
         fp32_eq = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         fam_ms = sum(prof.ms[v] for v in range(3)); fam_fl = sum(prof.flops[v] for v in range(3))
-        # split-bf16 kernel: the contraction at this accuracy IS six bf16 MFMA products per fp32 product, so the
-        # kernel's algorithmic work is 6 x (2 I J K) bf16 flops, priced against the dense bf16 MFMA peak
-        mult, peak = ({"split3": 6.0, "split2": 3.0, "bf16": 1.0, "split3_bwd2": 4.0}[mode], BF16_MFMA_PEAK_TFLOPS) if x6 else (1.0, FP32_MFMA_PEAK_TFLOPS)
+        # split kernel: the contraction at this accuracy IS `mult` 16-bit MFMA products per fp32 product (3 on fp16
+        # planes of scaled operands, 6 on bf16 planes), so the kernel's algorithmic work is mult x (2 I J K) flops,
+        # priced against the dense bf16/fp16 MFMA peak
+        mult, peak = ({"split3": 6.0, "f16x2": 3.0, "split2": 3.0, "bf16": 1.0, "split3_bwd2": 4.0}[mode], BF16_MFMA_PEAK_TFLOPS) if x6 else (1.0, FP32_MFMA_PEAK_TFLOPS)
         achieved = fp32_eq * mult
         # HBM bytes per launch of that kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
         # the MI355X guide), measured on this exact workload: profiles/r01/pmc_hbm_traffic.md
-        traffic = 1.694e9 if (mode == "split3" and args.rays == 4096 and args.samples == 64) else None
+        traffic = 1.352e9 if (mode == "f16x2" and args.rays == 4096 and args.samples == 64) else None
         line["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "kernel": ("snerf::gemm_x6_kernel<false,true,NP,128> (split-bf16: NP = 3 bf16 planes per fp32 operand, 6 x v_mfma_f32_32x32x16_bf16 per "
-                       "32x32x16 block, fp32 accumulate; forward X.W^T and dX launches)" if x6 else
+            "kernel": (("snerf::gemm_x6_kernel<false,true,2,128,1> (two fp16 planes of power-of-two-scaled fp32 operands, hh + hl + lh = 3 x "
+                        "v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulate; forward X.W^T and dX launches)" if mode == "f16x2" else
+                        "snerf::gemm_x6_kernel<false,true,NP,128> (split-bf16: NP bf16 planes per fp32 operand, 6 / 3 / 1 x v_mfma_f32_32x32x16_bf16 per "
+                        "32x32x16 block for NP = 3 / 2 / 1, fp32 accumulate; forward X.W^T and dX launches)") if x6 else
                        "snerf::gemm_kernel<128,128,64,64,false,false> (v_mfma_f32_32x32x2_f32)"),
             "fp32_equivalent_tflops": fp32_eq, "vs_fp32_mfma_peak": fp32_eq / FP32_MFMA_PEAK_TFLOPS,
             "launches": int(n), "avg_launch_ms": ms / max(n, 1),

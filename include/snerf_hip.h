@@ -58,6 +58,11 @@ extern "C" {
                                    arithmetic (the 1e-4 output bar), the dX / dW contractions use two planes (gradients
                                    ~1e-4 relative) */
 
+#define SNERF_FLAG_F16X2 64u   /* fp32-class arithmetic on HALF the matrix work: every operand is scaled by a power of two taken
+                                  from its |max| (tracked on the device), split into two fp16 planes (22 significant bits) and
+                                  contracted as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation; the
+                                  dropped lo*lo term is 2^-22 relative, below an fp32 GEMM's own rounding (normwise) */
+
 /* Model + batch description.  Field names follow the reference config
  * (configs/pipelines/rs_semantic.toml:13-67, semantic/pipelines/rs_semantic.py:125-141). */
 typedef struct SnerfDesc {

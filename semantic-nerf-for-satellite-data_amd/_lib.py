@@ -13,7 +13,8 @@ FLAG_BF16 = 8       # reduced precision: one bf16 plane per operand (precision =
 FLAG_BF16X3 = 16    # reduced precision: two bf16 planes, three products (float32_matmul_precision "high")
 # ModelSpec.mfma -> SnerfDesc.flags
 FLAG_BWD_BF16X3 = 32  # reduced precision (two planes) in the backward contractions only
-MFMA_FLAGS = {"split3": 0, "fp32": FLAG_FP32_MFMA, "split2": FLAG_BF16X3, "bf16": FLAG_BF16, "split3_bwd2": FLAG_BWD_BF16X3}
+FLAG_F16X2 = 64       # fp32-class on half the matrix work: two fp16 planes of power-of-two-scaled operands
+MFMA_FLAGS = {"f16x2": FLAG_F16X2, "split3": 0, "fp32": FLAG_FP32_MFMA, "split2": FLAG_BF16X3, "bf16": FLAG_BF16, "split3_bwd2": FLAG_BWD_BF16X3}
 
 _fp = C.POINTER(C.c_float)
 

@@ -153,26 +153,75 @@ int launch_transpose(const float* src, int ld_src, int rows, int cols, float* ds
 // running residual: x = hi + mid + lo to 2^-26 relative), stored k-tile-major [ld/16][rows][16] with the LDS image's
 // swizzle baked in (the two 8-k halves of a row swap on rows with bit 3 set): a 128-row x 16-k tile is then 4 KB
 // of contiguous memory that the GEMM copies to LDS verbatim.  Plane p at planes + p*plane_stride.
+// fmt 1: two fp16 planes of x * scale, scale = the power of two that scale_of_max() derives from the matrix's |max|
+// slots (the GEMM derives the same scale from the same slots and divides it out of the accumulator).
+__device__ __forceinline__ float scale_of_slots(const unsigned* __restrict__ slots) {
+  unsigned m = 0u;
+  for (int i = 0; i < 64; ++i) { const unsigned q = slots[i]; m = q > m ? q : m; }
+  if (m == 0u || m >= 0x7f800000u) return 1.f;
+  int se = 13 - ((int)(m >> 23) - 127);
+  se = se < -60 ? -60 : (se > 60 ? 60 : se);
+  return __uint_as_float((unsigned)(127 + se) << 23);
+}
+
 __global__ void split_planes_kernel(const float* __restrict__ x, int rows, int ld, unsigned short* __restrict__ planes,
-                                    size_t plane_stride) {
+                                    size_t plane_stride, int fmt, const unsigned* __restrict__ slots) {
+  __shared__ float s_scale;
+  if (fmt == 1) {
+    if (threadIdx.x == 0) s_scale = scale_of_slots(slots);
+    __syncthreads();
+  }
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)rows * ld) return;
   const int r = (int)(i / ld), k = (int)(i - (size_t)r * ld);
+  const int kk = k & 15;
+  const size_t o = ((size_t)(k >> 4) * rows + r) * 16 + ((((kk >> 3) ^ (r >> 3)) & 1) << 3) + (kk & 7);
+  if (fmt == 1) {
+    const float v = x[i] * s_scale;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    planes[o] = __builtin_bit_cast(unsigned short, h);
+    planes[plane_stride + o] = __builtin_bit_cast(unsigned short, l);
+    return;
+  }
   const float v = x[i];
   const __bf16 h = (__bf16)v;
   const float r1 = v - (float)h;
   const __bf16 m = (__bf16)r1;
   const __bf16 l = (__bf16)(r1 - (float)m);
-  const int kk = k & 15;
-  const size_t o = ((size_t)(k >> 4) * rows + r) * 16 + ((((kk >> 3) ^ (r >> 3)) & 1) << 3) + (kk & 7);
   planes[o] = __builtin_bit_cast(unsigned short, h);
   planes[plane_stride + o] = __builtin_bit_cast(unsigned short, m);
   planes[2 * plane_stride + o] = __builtin_bit_cast(unsigned short, l);
 }
 
-int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes, size_t plane_stride, hipStream_t st) {
+int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes, size_t plane_stride, hipStream_t st,
+                        int fmt, const unsigned* slots) {
   const size_t n = (size_t)rows * ld;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, rows, ld, planes, plane_stride);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, rows, ld, planes, plane_stride,
+                     fmt, slots);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
+// |max| of a rows x cols block (leading dimension ld) into 64 slots of float bits (atomicMax; order-independent, so
+// deterministic).  Slots must have been zeroed.  Used for tensors whose producer is not a GEMM epilogue.
+__global__ void absmax_kernel(const float* __restrict__ x, int rows, int cols, int ld, unsigned* __restrict__ slots) {
+  const size_t n = (size_t)rows * cols;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t r = i / cols;
+    m = fmaxf(m, fabsf(x[r * ld + (i - r * cols)]));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), __float_as_uint(m));
+}
+
+int launch_absmax(const float* x, int rows, int cols, int ld, unsigned* slots, hipStream_t st) {
+  const size_t n = (size_t)rows * cols;
+  if (n == 0) return 0;
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, st, x, rows, cols, ld, slots);
   SNERF_LAUNCH_CHECK();
   return 0;
 }

@@ -26,6 +26,7 @@ struct KArgs {
   float* C; float* C2;
   const float* bias; const float* aux; float* colsum;
   unsigned* C2s; const unsigned* auxs; int sign_col0, sign_groups;
+  const unsigned* amaxA; const unsigned* amaxA2; const unsigned* amaxB; unsigned* cmax;
   unsigned bytesA, bytesA2, bytesB;
   const unsigned short* Bpl; unsigned pl_stride_bytes; unsigned bytesBpl; int bt_rows, bt_row0, bt_k0;
   int lda, lda2, Ka, ldb, I, J, K, ldc, ldaux, ldcs;
@@ -35,6 +36,24 @@ struct KArgs {
   unsigned long long slab_stride;
   int tiles_i, tiles_j;
 };
+
+// ---- operand scaling of the fp16-plane mode --------------------------------------------------------------------
+constexpr int MAX_SLOTS = 64;   // |max| of a tensor = max over 64 slots of float bits (spreads the atomics)
+// power of two s with max * s in [2^13, 2^14) (fp16 overflows at 2^16), clamped to 2^+-60; 1 for an empty / non-finite max
+__device__ __forceinline__ float scale_of_max(unsigned maxbits) {
+  if (maxbits == 0u || maxbits >= 0x7f800000u) return 1.f;
+  int se = 13 - ((int)(maxbits >> 23) - 127);
+  se = se < -60 ? -60 : (se > 60 ? 60 : se);
+  return __uint_as_float((unsigned)(127 + se) << 23);
+}
+// wave-uniform max of one or two slot arrays (nullptr = none)
+__device__ __forceinline__ unsigned slots_max(const unsigned* s1, const unsigned* s2, int lane) {
+  unsigned m = s1 ? s1[lane] : 0u;
+  if (s2) { const unsigned m2 = s2[lane]; m = m2 > m ? m2 : m; }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const unsigned q = __shfl_xor(m, o, 64); m = q > m ? q : m; }
+  return m;
+}
 
 // Workgroup -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), and the J-tiles of
 // one I-tile re-read the same A rows, so give each XCD group runs of consecutive J-tiles of the
@@ -143,6 +162,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
   const int rrow = lane / LPR, c4 = 4 * (lane % LPR);
   const int col = j0 + wj0 + c4;
   const bool col_ok = col < p.J;     // J % 4 == 0 (host check): a float4 is entirely inside or outside
+  float vmax = 0.f;  // |max| of what this wave stores (p.cmax)
   float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias != nullptr && col_ok) bj = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll
@@ -203,6 +223,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
         if (ok) {
           *reinterpret_cast<float4*>(C + off) = v;
           cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
       }
       if (WJ == 64 && p.C2s != nullptr && col_ok) p.C2s[sidx] = sbits;
@@ -218,6 +239,11 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
       }
 #endif
     }
+  }
+  if (p.cmax != nullptr) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if (lane == 0 && vmax > 0.f) atomicMax(p.cmax + (blockIdx.x & (MAX_SLOTS - 1)), __float_as_uint(vmax));
   }
 }
 

@@ -24,6 +24,8 @@ namespace snerf {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // Two tile configurations share the kernel: BT = 128 (128 x 128 tile, 4 waves of 64 x 64, 3 workgroups per CU)
 // and BT = 256 (256 x 256 tile, 8 waves of 128 x 64 in a 2 x 4 grid, one workgroup per CU = 2 waves per SIMD with
@@ -55,6 +57,21 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4& hi, bf16x4& mid, 
   }
 }
 
+// FMT 1: 4 fp32 (times the operand's power-of-two scale) -> 2 planes x 4 fp16: hi = fp16(x), lo = fp16(x - hi).
+// 22 significant bits of the scaled value; with hh + hl + lh the dropped lo*lo term is 2^-22 relative -- below the
+// rounding of an fp32 GEMM.  Returned as bf16x4 bit patterns (the LDS image is format-agnostic 16-bit data).
+__device__ __forceinline__ void split2h(const float4 v, float scale, bf16x4& hi, bf16x4& lo) {
+  const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+  f16x4 h, l;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h[i] = (_Float16)x[i];
+    l[i] = (_Float16)(x[i] - (float)h[i]);
+  }
+  hi = __builtin_bit_cast(bf16x4, h);
+  lo = __builtin_bit_cast(bf16x4, l);
+}
+
 // byte offset inside one plane
 __device__ __forceinline__ int kc_off(int row, int k) {  // k multiple of 4
   return row * 32 + ((((k >> 3) ^ (row >> 3)) & 1) << 4) + ((k >> 2) & 1) * 8;
@@ -64,15 +81,16 @@ __device__ __forceinline__ int ic_off(int row, int k) {  // row multiple of 4
   return k * (2 * BT) + ((row ^ (32 * (k & 3))) << 1);
 }
 
-template <bool IC, int NP, int BT>
-__device__ __forceinline__ void store_planes(const float4 (&v)[2], char* __restrict__ op, int t) {
+template <bool IC, int NP, int BT, int FMT>
+__device__ __forceinline__ void store_planes(const float4 (&v)[2], char* __restrict__ op, int t, float scale) {
   using T = TileCfg<BT>;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     int il, kl;
     tile_coord<BT, IC, T::NTH>(t, r, il, kl);
     bf16x4 hi, mid, lo;
-    split3(v[r], hi, mid, lo);
+    if (FMT == 1) split2h(v[r], scale, hi, mid);
+    else split3(v[r], hi, mid, lo);
     const int o = IC ? ic_off<BT>(il, kl) : kc_off(il, kl);
     *reinterpret_cast<bf16x4*>(op + o) = hi;
     if (NP > 1) *reinterpret_cast<bf16x4*>(op + T::PLANE_BYTES + o) = mid;
@@ -106,7 +124,8 @@ __device__ __forceinline__ bf16x8 load_frag(const char* __restrict__ pl, int r0,
 // (8 k of one row) per plane from global to LDS with no conversion work.
 // NP bf16 planes per operand: 3 = fp32-class (six products, the default); 2 = hi | mid with the three products
 // hh, hm, mh (~16 significant bits); 1 = plain bf16 operands, one product.
-template <bool IC, bool BPL, int NP, int BT>
+// FMT 1 (NP = 2): fp16 planes, operands scaled by powers of two derived from their |max| slots, products hh + hl + lh.
+template <bool IC, bool BPL, int NP, int BT, int FMT = 0>
 __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6_kernel(const KArgs p) {
   using T = TileCfg<BT>;
   constexpr int MI = T::MI, NJ = T::NJ, NTH = T::NTH;
@@ -120,6 +139,11 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wi0 = (wave / T::WAVES_J) * T::WI, wj0 = (wave % T::WAVES_J) * T::WJ;
+  float sa = 1.f, sb = 1.f;   // operand scales (FMT 1); pre-split weight planes carry sb already
+  if (FMT == 1) {
+    sa = scale_of_max(slots_max(p.amaxA, p.amaxA2, lane));
+    sb = scale_of_max(slots_max(p.amaxB, nullptr, lane));
+  }
   __builtin_amdgcn_s_setprio(2);  // non-MFMA phases at raised priority (see gemm.hip)
   int ti, tj;
   int kBeg = 0, kEnd = p.K;
@@ -188,12 +212,12 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
     }
   };
   auto store = [&](const Tile& r, char* stage) {
-    store_planes<IC, NP, BT>(r.ra, stage, t);
+    store_planes<IC, NP, BT, FMT>(r.ra, stage, t, sa);
     if (BPL) {
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x4*>(stage + OPERAND_BYTES + pl * PLANE_BYTES + 16 * t) = r.rbp[pl];
     } else {
-      store_planes<IC, NP, BT>(r.rb, stage + OPERAND_BYTES, t);
+      store_planes<IC, NP, BT, FMT>(r.rb, stage + OPERAND_BYTES, t, sb);
     }
   };
   // One k-tile: MFMAs on LDS stage kt & 1; `r` (tile kt+1, requested a full iteration earlier) is split and stored
@@ -220,6 +244,15 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
     auto block = [&](int mi, int nj) {
       const bf16x8 (&am)[NP] = a[mi & 1];
       f32x16 c = acc[mi][nj];
+      if constexpr (FMT == 1) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, am[0]), al = __builtin_bit_cast(f16x8, am[1]);
+        const f16x8 bh = __builtin_bit_cast(f16x8, b[0][nj]), bl = __builtin_bit_cast(f16x8, b[1][nj]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+        acc[mi][nj] = c;
+        return;
+      }
       if constexpr (NP > 2) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], b[1][nj], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], b[2][nj], c, 0, 0, 0);
@@ -283,19 +316,33 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
   { float sum = 0.f; for (int mi = 0; mi < MI; ++mi) for (int nj = 0; nj < NJ; ++nj) for (int r = 0; r < 16; ++r) sum += acc[mi][nj][r];
     if (sum == 12345.678f) C[0] = sum; return; }
 #endif
+  if (FMT == 1) {
+    const float inv = 1.f / (sa * sb);   // exact: powers of two, |exponent| <= 120
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][nj][r] *= inv;
+  }
   gemm_epilogue<MI, NJ, T::WJ>(acc, reinterpret_cast<float*>(lds), wave, lane, i0 + wi0, j0 + wj0, p, C);
 }
 
-template <int NP, int BT>
+template <int NP, int BT, int FMT = 0>
 static void launch_np(bool ic, bool b_planes, const KArgs& p, dim3 grid, hipStream_t stream) {
   const dim3 block(TileCfg<BT>::NTH);
-  if (ic) hipLaunchKernelGGL((gemm_x6_kernel<true, false, NP, BT>), grid, block, 0, stream, p);
-  else if (b_planes) hipLaunchKernelGGL((gemm_x6_kernel<false, true, NP, BT>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((gemm_x6_kernel<false, false, NP, BT>), grid, block, 0, stream, p);
+  if (ic) hipLaunchKernelGGL((gemm_x6_kernel<true, false, NP, BT, FMT>), grid, block, 0, stream, p);
+  else if (b_planes) hipLaunchKernelGGL((gemm_x6_kernel<false, true, NP, BT, FMT>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((gemm_x6_kernel<false, false, NP, BT, FMT>), grid, block, 0, stream, p);
 }
 
-// tile: 128 or 256 (p.tiles_i / p.tiles_j and the grid must have been computed for it)
-void launch_x6(bool ic, bool b_planes, int planes, int tile, const KArgs& p, dim3 grid, hipStream_t stream) {
+// tile: 128 or 256 (p.tiles_i / p.tiles_j and the grid must have been computed for it); fmt 1 = fp16 planes (planes = 2)
+void launch_x6(bool ic, bool b_planes, int planes, int fmt, int tile, const KArgs& p, dim3 grid, hipStream_t stream) {
+  if (fmt == 1) {
+    if (tile == 256) launch_np<2, 256, 1>(ic, b_planes, p, grid, stream);
+    else launch_np<2, 128, 1>(ic, b_planes, p, grid, stream);
+    return;
+  }
   if (tile == 256) {
     if (planes == 1) launch_np<1, 256>(ic, b_planes, p, grid, stream);
     else if (planes == 2) launch_np<2, 256>(ic, b_planes, p, grid, stream);

@@ -19,14 +19,19 @@ from . import _lib
 BASE_FLAGS = _lib.MFMA_FLAGS.get(os.environ.get("SNERF_MFMA", "").lower())
 
 
+DEFAULT_MFMA = "f16x2"
+
+
 def mfma_mode(pipeline_cfg=None, run_cfg=None) -> str:
     """Matrix-unit arithmetic of the dense layers from the reference's two precision knobs:
     `precision` (baseline/pipelines/nerf.py:65; 16 = half precision) and the run config's
     `float32_matmul_precision` (framework/configs.py:26, applied at framework/pipelines.py:254-256).  The build adds
-    the pipeline field `mfma_precision`: "split3" (default: three bf16 planes per fp32 operand, fp32-class results --
-    the 1e-4 parity bar), "fp32" (v_mfma_f32_32x32x2_f32), "split2" (two planes, ~16 significant bits: what
-    torch calls "high"), "bf16" (one plane: "medium" / precision = 16), or "auto" = follow float32_matmul_precision."""
-    mode = getattr(pipeline_cfg, "mfma_precision", "split3")
+    the pipeline field `mfma_precision`: "f16x2" (default: two fp16 planes of power-of-two-scaled operands, three
+    products, fp32-class results at half the matrix work of split3), "split3" (three bf16 planes per fp32 operand, six
+    products: fp32-class with per-element 24-bit operands), "fp32" (v_mfma_f32_32x32x2_f32), "split3_bwd2" / "split2"
+    (two bf16 planes, ~16 significant bits: what torch calls "high"; backward only / everywhere), "bf16" (one plane:
+    "medium" / precision = 16), or "auto" = follow float32_matmul_precision (highest / high / medium)."""
+    mode = getattr(pipeline_cfg, "mfma_precision", DEFAULT_MFMA)
     if getattr(pipeline_cfg, "precision", 32) == 16:
         return "bf16"
     if mode == "auto":
@@ -67,7 +72,7 @@ class ModelSpec:
     use_tj_for_s: bool = False
     use_separate_beta_for_s: bool = False
     use_separate_tj_for_semantic: bool = False
-    mfma: str = "split3"        # see mfma_mode()
+    mfma: str = "f16x2"         # see mfma_mode()
 
     @staticmethod
     def from_pipeline_cfg(pc, n_classes: int, model: str = "semantic", run_cfg=None) -> "ModelSpec":

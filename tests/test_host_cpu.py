@@ -11,14 +11,15 @@ def test_mfma_mode_mapping():
     """precision / float32_matmul_precision / mfma_precision -> matrix arithmetic (ops.mfma_mode)"""
     from types import SimpleNamespace as NS
     from snerf_amd import ops, _lib
-    assert ops.mfma_mode(NS(precision=32), None) == "split3"
+    assert ops.mfma_mode(NS(precision=32), None) == "f16x2"
     assert ops.mfma_mode(NS(precision=16), None) == "bf16"
     assert ops.mfma_mode(NS(precision=32, mfma_precision="fp32"), None) == "fp32"
     for run, want in (("highest", "split3"), ("high", "split2"), ("medium", "bf16")):
         assert ops.mfma_mode(NS(precision=32, mfma_precision="auto"), NS(float32_matmul_precision=run)) == want
     d = ops.ModelSpec(mfma="split2").desc(16, 8)
     assert d.flags & _lib.FLAG_BF16X3
-    assert ops.ModelSpec().desc(16, 8).flags == 0
+    assert ops.ModelSpec().desc(16, 8).flags == _lib.FLAG_F16X2          # default: fp32-class on fp16 planes
+    assert ops.ModelSpec(mfma="split3").desc(16, 8).flags == 0
 
 import torch
 
