@@ -64,6 +64,41 @@ __device__ __forceinline__ void sincos_acc(float x, float* s, float* c) {
   *c = cc;
 }
 
+// sin(x) and the SIGN of cos(x) only -- what a SIREN layer needs (the backward pass rebuilds |cos| = sqrt(1 - sin^2)).
+// Reduction by pi (four-part Cody-Waite, exact for |k| < 2^15) to r in [-pi/2, pi/2], ONE odd polynomial up to r^11
+// (fit error 2e-11; fp32 evaluation <= 1.9 ulp / 1.1e-7 abs against fp64 for |x| <= 3e4), sin x = (-1)^k sin r and
+// cos x < 0 iff k is odd, corrected when rounding of k left |r| a hair above pi/2.  ~17 VALU against ~28 for
+// sincos_acc.  Larger arguments reduce in double like sincos_acc.
+__device__ __forceinline__ float sin_signcos(float x, bool* cos_neg) {
+  float r;
+  int k;
+  if (__builtin_expect(fabsf(x) <= 30000.f, 1)) {
+    const float kf = rintf(x * 0.31830988618379067154f);  // x / pi
+    k = (int)kf;
+    r = fmaf(kf, -3.140625f, x);
+    r = fmaf(kf, -9.67502593994140625e-4f, r);
+    r = fmaf(kf, -1.509958025280866e-07f, r);
+    r = fmaf(kf, 3.4302490200117638e-15f, r);
+  } else {
+    const double xd = (double)x;
+    const double kd = rint(xd * 0.31830988618379067154);
+    double rd = fma(kd, -3.14159265346825122833e+00, xd);  // 2 x the 33-bit pieces of pi/2 (fdlibm pio2_1..3)
+    rd = fma(kd, -1.21542010126079319532e-10, rd);
+    rd = fma(kd, -4.04453249742233291160e-21, rd);
+    r = (float)rd;
+    k = (int)((long long)kd & 1);
+  }
+  const float r2 = r * r;
+  float p = fmaf(r2, -2.5028294103890403e-08f, 2.755689592959243e-06f);
+  p = fmaf(p, r2, -0.00019841265748254955f);
+  p = fmaf(p, r2, 0.008333333767950535f);
+  p = fmaf(p, r2, -0.1666666716337204f);
+  const float s = fmaf(r * r2, p, r);
+  const bool odd = k & 1;
+  *cos_neg = odd != (fabsf(r) > 1.57079637f);
+  return odd ? -s : s;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

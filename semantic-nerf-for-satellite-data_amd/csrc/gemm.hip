@@ -199,7 +199,7 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel(const KArgs p) {
     return;
   }
 #endif
-  gemm_epilogue<MI, NJ, WJ>(acc, lds, wave, lane, i0 + wi0, j0 + wj0, p, C);
+  gemm_epilogue_dispatch<MI, NJ, WJ>(acc, lds, wave, lane, i0 + wi0, j0 + wj0, p, C);
 #ifdef SNERF_ABL_CLOCK
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (t == 0 && p.colsum != nullptr && p.aux_mode == AUX_NONE) {
@@ -242,6 +242,8 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
   p.bias = g.bias; p.aux = g.aux; p.colsum = g.colsum;
   p.C2s = g.C2s; p.auxs = g.aux_sign; p.sign_col0 = g.aux_sign ? g.sign_col0 : 0;
   p.sign_groups = ((g.aux_sign ? g.ldaux : g.ldc) + 63) / 64;
+  static const unsigned epi_mask = getenv("SNERF_FAST_EPI") ? (unsigned)atoi(getenv("SNERF_FAST_EPI")) : 29u;  // default: all but the SIREN forward kind (measured slower: 43.3 vs 39.6 ms per step); env for A/B
+  p.epi_mask = epi_mask;
   p.amaxA = g.a_max; p.amaxA2 = g.A2 ? g.a2_max : nullptr; p.amaxB = g.b_max; p.cmax = g.c_max;
   p.lda = g.lda; p.lda2 = g.A2 ? g.lda2 : g.lda; p.Ka = g.A2 ? g.Ka : 0x7fffffff;
   p.ldb = g.ldb; p.I = g.I; p.J = g.J; p.K = g.K; p.ldc = g.ldc; p.ldaux = g.ldaux; p.ldcs = g.ldcs;

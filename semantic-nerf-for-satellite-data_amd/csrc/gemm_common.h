@@ -27,6 +27,7 @@ struct KArgs {
   const float* bias; const float* aux; float* colsum;
   unsigned* C2s; const unsigned* auxs; int sign_col0, sign_groups;
   const unsigned* amaxA; const unsigned* amaxA2; const unsigned* amaxB; unsigned* cmax;
+  unsigned epi_mask;   // which (act, aux) kinds take the straight-line epilogue: bit 0 plain, 1 sin, 2 relu, 3 sinrec, 4 relu mask
   unsigned bytesA, bytesA2, bytesB;
   const unsigned short* Bpl; unsigned pl_stride_bytes; unsigned bytesBpl; int bt_rows, bt_row0, bt_k0;
   int lda, lda2, Ka, ldb, I, J, K, ldc, ldaux, ldcs;
@@ -151,7 +152,7 @@ __device__ __forceinline__ srd_t srd_krows(const float* P, int ld, int kBeg, int
 // bytes per row; bias-gradient column sums by a butterfly over the row bits.
 template <int MI, int NJ, int WJ>
 __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float* __restrict__ lds, int wave, int lane,
-                                              int row0, int col0, const KArgs& p, float* __restrict__ C) {
+                                              int row0, int col0, const KArgs& p, float* __restrict__ C, float acc_scale = 1.f) {
   constexpr int EP = WJ + 4;
   constexpr int EPI = 32 * EP;
   const int i0 = row0, wi0 = 0, j0 = col0, wj0 = 0;
@@ -173,7 +174,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
       for (int nj = 0; nj < NJ; ++nj)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + 32 * nj + lc] = acc[mi][nj][r];
+          strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + 32 * nj + lc] = acc[mi][nj][r] * acc_scale;
       float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
       // sign words of the activation derivative (see GemmArgs::C2s): one word per lane and 32-row block
       unsigned sbits = 0u, sword = 0u;
@@ -191,14 +192,19 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
         float4 v = *reinterpret_cast<const float4*>(&strip[rl * EP + c4]);
         v.x += bj.x; v.y += bj.y; v.z += bj.z; v.w += bj.w;
         const size_t off = (size_t)row * p.ldc + col;
-        if (p.act == ACT_SIN) {
+        if (p.act == ACT_SIN && p.C2 == nullptr) {
+          // sin and the sign of cos only (the derivative is rebuilt from h in the backward epilogue)
+          bool n0, n1, n2, n3;
+          v.x = sin_signcos(p.w0 * v.x, &n0); v.y = sin_signcos(p.w0 * v.y, &n1);
+          v.z = sin_signcos(p.w0 * v.z, &n2); v.w = sin_signcos(p.w0 * v.w, &n3);
+          if (WJ == 64 && p.C2s != nullptr)
+            sbits |= ((n0 ? 1u : 0u) | (n1 ? 2u : 0u) | (n2 ? 4u : 0u) | (n3 ? 8u : 0u)) << (4 * ps);
+        } else if (p.act == ACT_SIN) {   // diagnostic form: w0*cos stored as floats (SNERF_DERIV=float)
           float4 cn;
           sincos_acc(p.w0 * v.x, &v.x, &cn.x);
           sincos_acc(p.w0 * v.y, &v.y, &cn.y);
           sincos_acc(p.w0 * v.z, &v.z, &cn.z);
           sincos_acc(p.w0 * v.w, &v.w, &cn.w);
-          if (WJ == 64 && p.C2s != nullptr)
-            sbits |= ((cn.x < 0.f ? 1u : 0u) | (cn.y < 0.f ? 2u : 0u) | (cn.z < 0.f ? 4u : 0u) | (cn.w < 0.f ? 8u : 0u)) << (4 * ps);
           if (p.C2 != nullptr && ok) {
             cn.x *= p.w0; cn.y *= p.w0; cn.z *= p.w0; cn.w *= p.w0;
             *reinterpret_cast<float4*>(p.C2 + off) = cn;
@@ -221,7 +227,14 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
           else { v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f; }
         }
         if (ok) {
+#ifdef SNERF_ABL_NOSTORE
+          asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#elif defined(SNERF_ABL_NTSTORE)
+          __builtin_nontemporal_store(v.x, C + off); __builtin_nontemporal_store(v.y, C + off + 1);
+          __builtin_nontemporal_store(v.z, C + off + 2); __builtin_nontemporal_store(v.w, C + off + 3);
+#else
           *reinterpret_cast<float4*>(C + off) = v;
+#endif
           cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
           vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
@@ -245,6 +258,127 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
     for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
     if (lane == 0 && vmax > 0.f) atomicMax(p.cmax + (blockIdx.x & (MAX_SLOTS - 1)), __float_as_uint(vmax));
   }
+}
+
+// ---- straight-line epilogue (64-wide wave tiles) -----------------------------------------------------------------
+// Same arithmetic and layouts as gemm_epilogue, specialised at compile time on (ACT, AUX) so that the pass loop has
+// NO runtime branches: bounds are enforced by buffer descriptors (an out-of-range element gets the offset the hardware
+// rejects), the aux operand of a 32-row block is requested in one batch before the accumulators go through the LDS
+// strip, and the eight row stores of a block are issued back to back.  With branches in the loop the compiler has to
+// fall back to s_waitcnt vmcnt(0) after every load / before every LDS read: each of the 16 stores and aux loads of a
+// wave then cost a full memory round trip (measured: 24-32 k of a workgroup's 85-90 k cycles).
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void buf_store4(srd_t s, unsigned off, float4 v) {
+  u32x4s d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+  __builtin_amdgcn_raw_buffer_store_b128(d, s, off, 0, 0);
+}
+
+template <int MI, int NJ, int ACT, int AUX>
+__device__ __forceinline__ void gemm_epilogue_fast(const f32x16 (&acc)[MI][NJ], float* __restrict__ lds, int wave, int lane,
+                                                   int row0, int col0, const KArgs& p, float* __restrict__ C, float acc_scale) {
+  constexpr int WJ = 64, EP = WJ + 4, EPI = 32 * EP, LPR = 16, RPP = 4, NPASS = 8;
+  static_assert(NJ == 2, "64-wide wave tile");
+  float* strip = lds + wave * EPI;
+  const int lc = lane & 31, lh = lane >> 5;
+  const int rrow = lane / LPR, c4 = 4 * (lane % LPR);
+  const int col = col0 + c4;
+  const bool col_ok = col < p.J;
+  // descriptors based at the wave tile's first element; offsets are tile-relative (< 2^31 by launch_gemm's span check)
+  const srd_t srdC = make_srd(C + (size_t)row0 * p.ldc + col0, 0xFFFFFFE0u);
+  const srd_t srdAux = make_srd(AUX != AUX_NONE ? p.aux + (size_t)row0 * p.ldaux + col0 : nullptr, AUX != AUX_NONE ? 0xFFFFFFE0u : 0u);
+  float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias != nullptr && col_ok) bj = *reinterpret_cast<const float4*>(p.bias + col);
+  const bool signs_out = ACT == ACT_SIN && p.C2s != nullptr;
+  const srd_t srdS = make_srd(signs_out ? p.C2s : nullptr, signs_out ? 0xFFFFFFE0u : 0u);
+  float vmax = 0.f;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int rbase = row0 + 32 * mi;
+    // aux of the whole 32-row block in flight before the LDS round trip (offsets recomputed per pass: registers)
+    auto okp = [&](int ps) { return col_ok && (row0 + 32 * mi + rrow + RPP * ps) < p.I; };
+    float4 ax[AUX != AUX_NONE ? NPASS : 1];
+    unsigned sword = 0u;
+    const int cabs = col + p.sign_col0;
+    const size_t sidx = ((size_t)(rbase >> 5) * p.sign_groups + (cabs >> 6)) * 64 + rrow * 16 + ((cabs >> 2) & 15);
+    if (AUX != AUX_NONE) {
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps)
+        ax[ps] = buf_load4(srdAux, okp(ps) ? ((unsigned)(32 * mi + rrow + RPP * ps) * (unsigned)p.ldaux + (unsigned)c4) * 4u : OOB);
+      if (AUX == AUX_SINREC) sword = p.auxs[(col_ok && rbase < p.I) ? sidx : 0];
+    }
+#pragma unroll
+    for (int nj = 0; nj < NJ; ++nj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP + 32 * nj + lc] = acc[mi][nj][r] * acc_scale;
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned sbits = 0u;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const bool ok = okp(ps);
+      float4 w = *reinterpret_cast<const float4*>(&strip[(rrow + RPP * ps) * EP + c4]);
+      w.x += bj.x; w.y += bj.y; w.z += bj.z; w.w += bj.w;
+      if (ACT == ACT_SIN) {
+        bool n0, n1, n2, n3;
+        w.x = sin_signcos(p.w0 * w.x, &n0); w.y = sin_signcos(p.w0 * w.y, &n1);
+        w.z = sin_signcos(p.w0 * w.z, &n2); w.w = sin_signcos(p.w0 * w.w, &n3);
+        sbits |= ((n0 ? 1u : 0u) | (n1 ? 2u : 0u) | (n2 ? 4u : 0u) | (n3 ? 8u : 0u)) << (4 * ps);
+      } else if (ACT == ACT_RELU) {
+        w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
+      }
+      if (AUX == AUX_SINREC) {
+        const float4 x = ax[ps];
+        const unsigned nib = sword >> (4 * ps);
+        const float dx = p.w0 * sqrtf(fmaxf(fmaf(-x.x, x.x, 1.f), 0.f)), dy = p.w0 * sqrtf(fmaxf(fmaf(-x.y, x.y, 1.f), 0.f));
+        const float dz = p.w0 * sqrtf(fmaxf(fmaf(-x.z, x.z, 1.f), 0.f)), dw = p.w0 * sqrtf(fmaxf(fmaf(-x.w, x.w, 1.f), 0.f));
+        w.x *= (nib & 1u) ? -dx : dx; w.y *= (nib & 2u) ? -dy : dy;
+        w.z *= (nib & 4u) ? -dz : dz; w.w *= (nib & 8u) ? -dw : dw;
+      } else if (AUX == AUX_RELU_MASK) {
+        const float4 x = ax[ps];
+        w.x = x.x > 0.f ? w.x : 0.f; w.y = x.y > 0.f ? w.y : 0.f; w.z = x.z > 0.f ? w.z : 0.f; w.w = x.w > 0.f ? w.w : 0.f;
+      }
+      if (!ok) w = make_float4(0.f, 0.f, 0.f, 0.f);    // keeps column sums / max clean; the store is rejected anyway
+      cs.x += w.x; cs.y += w.y; cs.z += w.z; cs.w += w.w;
+      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
+      buf_store4(srdC, ok ? ((unsigned)(32 * mi + rrow + RPP * ps) * (unsigned)p.ldc + (unsigned)c4) * 4u : OOB, w);
+    }
+    if (signs_out) __builtin_amdgcn_raw_buffer_store_b32(sbits, srdS, (col_ok && rbase < p.I) ? (unsigned)(sidx * 4) : OOB, 0, 0);
+    if (p.colsum != nullptr) {   // wave-uniform
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
+        cs.z += __shfl_xor(cs.z, o, 64); cs.w += __shfl_xor(cs.w, o, 64);
+      }
+      if (lane < LPR && col_ok && rbase < p.I) *reinterpret_cast<float4*>(p.colsum + (size_t)(rbase >> 5) * p.ldcs + col) = cs;
+    }
+  }
+  if (p.cmax != nullptr) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+    if (lane == 0 && vmax > 0.f) atomicMax(p.cmax + (blockIdx.x & (MAX_SLOTS - 1)), __float_as_uint(vmax));
+  }
+}
+
+// Picks the straight-line epilogue for the (act, aux) pairs the passes use; anything else (the float-derivative
+// diagnostics, AUX_MUL) goes through the general gemm_epilogue.
+template <int MI, int NJ, int WJ>
+__device__ __forceinline__ void gemm_epilogue_dispatch(const f32x16 (&acc)[MI][NJ], float* __restrict__ lds, int wave, int lane,
+                                                       int row0, int col0, const KArgs& p, float* __restrict__ C,
+                                                       float acc_scale = 1.f) {
+  if constexpr (WJ == 64 && NJ == 2) {
+#ifndef SNERF_ABL_OLDEPI
+    const bool plain_store = p.C2 == nullptr && ((size_t)(MI * 32) * (size_t)(p.ldc > p.ldaux ? p.ldc : p.ldaux) * 4u < 0x7FFFFFFFu);
+    if (plain_store && p.aux_mode == AUX_NONE) {
+      if (p.act == ACT_NONE && (p.epi_mask & 1u)) return gemm_epilogue_fast<MI, NJ, ACT_NONE, AUX_NONE>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+      if (p.act == ACT_SIN && (p.epi_mask & 2u)) return gemm_epilogue_fast<MI, NJ, ACT_SIN, AUX_NONE>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+      if (p.act == ACT_RELU && (p.epi_mask & 4u)) return gemm_epilogue_fast<MI, NJ, ACT_RELU, AUX_NONE>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+    } else if (plain_store && p.act == ACT_NONE) {
+      if (p.aux_mode == AUX_SINREC && (p.epi_mask & 8u)) return gemm_epilogue_fast<MI, NJ, ACT_NONE, AUX_SINREC>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+      if (p.aux_mode == AUX_RELU_MASK && (p.epi_mask & 16u)) return gemm_epilogue_fast<MI, NJ, ACT_NONE, AUX_RELU_MASK>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+    }
+#endif
+  }
+  gemm_epilogue<MI, NJ, WJ>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
 }
 
 constexpr int epilogue_lds_floats(int WJ, int waves = 4) { return waves * 32 * (WJ + 4); }

@@ -139,6 +139,9 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wi0 = (wave / T::WAVES_J) * T::WI, wj0 = (wave % T::WAVES_J) * T::WJ;
+#ifdef SNERF_ABL_CLOCK
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   float sa = 1.f, sb = 1.f;   // operand scales (FMT 1); pre-split weight planes carry sb already
   if (FMT == 1) {
     sa = scale_of_max(slots_max(p.amaxA, p.amaxA2, lane));
@@ -304,28 +307,39 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
   fetch(kBeg + 2 * BK, r1);
   __syncthreads();
 
+#ifdef SNERF_ABL_CLOCK
+  const unsigned long long clk1 = __builtin_amdgcn_s_memtime();
+#endif
   __builtin_amdgcn_s_setprio(0);
   // k-tiles in pairs (an odd count runs one extra tile of zeros: fetches beyond kEnd return zeros)
   for (int kt = 0; kt < nkt; kt += 2) {
     ktile(kt, r0);
     ktile(kt + 1, r1);
   }
+#ifdef SNERF_ABL_CLOCK
+  const unsigned long long clk2 = __builtin_amdgcn_s_memtime();
+#endif
   __builtin_amdgcn_s_setprio(2);
   if (!wave_live) return;
 #ifdef SNERF_ABL_NOEPI
   { float sum = 0.f; for (int mi = 0; mi < MI; ++mi) for (int nj = 0; nj < NJ; ++nj) for (int r = 0; r < 16; ++r) sum += acc[mi][nj][r];
     if (sum == 12345.678f) C[0] = sum; return; }
 #endif
-  if (FMT == 1) {
-    const float inv = 1.f / (sa * sb);   // exact: powers of two, |exponent| <= 120
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int nj = 0; nj < NJ; ++nj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][nj][r] *= inv;
+  // FMT 1: the power-of-two operand scales are divided out while the accumulators pass through the LDS strip
+  const float inv = FMT == 1 ? 1.f / (sa * sb) : 1.f;   // exact: powers of two, |exponent| <= 120
+  gemm_epilogue_dispatch<MI, NJ, T::WJ>(acc, reinterpret_cast<float*>(lds), wave, lane, i0 + wi0, j0 + wj0, p, C, inv);
+#ifdef SNERF_ABL_CLOCK
+  {  // diagnostic build: cycle stamps of this workgroup's phases into the (otherwise unused) colsum buffer
+    const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long clk4 = __builtin_amdgcn_s_memtime();
+    if (t == 0 && p.colsum != nullptr) {
+      unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.colsum) + 8 * (size_t)blockIdx.x;
+      dbg[0] = clk1 - clk0; dbg[1] = clk2 - clk1; dbg[2] = clk3 - clk2; dbg[3] = clk4 - clk3;
+      dbg[4] = rt0; dbg[5] = __builtin_amdgcn_s_memrealtime(); dbg[6] = clk4 - clk0;
+    }
   }
-  gemm_epilogue<MI, NJ, T::WJ>(acc, reinterpret_cast<float*>(lds), wave, lane, i0 + wi0, j0 + wj0, p, C);
+#endif
 }
 
 template <int NP, int BT, int FMT = 0>

@@ -23,6 +23,7 @@ int main(int argc, char** argv) {
   const bool X6 = argc > 1 && argv[1][0] == 'x';
   const int PLANES = argc > 2 ? atoi(argv[2]) : 3;
   const int TILE = argc > 3 ? atoi(argv[3]) : 0;
+  const int FMT = argc > 4 ? atoi(argv[4]) : 0;
   const int P = 262144, W = 512;
   float *X, *Wt, *Y, *Y2, *dW, *cs;
   CK(hipMalloc(&X, (size_t)P * W * 4)); CK(hipMalloc(&Wt, (size_t)W * W * 4)); CK(hipMalloc(&Y, (size_t)P * W * 4));
@@ -34,53 +35,44 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(Wt, h.data(), (size_t)W * W * 4, hipMemcpyHostToDevice));
   unsigned short* Bplanes; CK(hipMalloc(&Bplanes, (size_t)3 * W * W * 2 + 4096)); CK(hipMemset(Bplanes, 0, (size_t)3 * W * W * 2));
   const double fl = 2.0 * P * W * W;
-  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
+  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
     time_gemm(g, 400); }  // clock / power state warm-up
-  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
+  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
     if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; }
     double t = time_gemm(g, 20); printf("fwd plain        %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.bias = Wt; g.act = ACT_SIN; g.w0 = 1.f;
     t = time_gemm(g, 20); printf("fwd sin          %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.C2 = Y2;
     t = time_gemm(g, 20); printf("fwd sin+cos out  %.3f ms %.1f TF\n", t, fl / t / 1e9); }
-  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.b_ic = true; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
+  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.b_ic = true; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
     double t = time_gemm(g, 20); printf("dX plain         %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.aux = Y2; g.ldaux = W; g.aux_mode = AUX_MUL; g.colsum = cs; g.ldcs = W;
     t = time_gemm(g, 20); printf("dX aux+colsum    %.3f ms %.1f TF\n", t, fl / t / 1e9); }
-  for (int ns : {32, 48, 64, 128}) { GemmArgs g; g.A = X; g.lda = W; g.a_ic = true; g.B = Y2; g.ldb = W; g.b_ic = true; g.I = W; g.J = W; g.K = P; g.C = dW; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
+  for (int ns : {32, 48, 64, 128}) { GemmArgs g; g.A = X; g.lda = W; g.a_ic = true; g.B = Y2; g.ldb = W; g.b_ic = true; g.I = W; g.J = W; g.K = P; g.C = dW; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
     g.k_split = ((P + ns - 1) / ns + 31) / 32 * 32; g.n_split = (P + g.k_split - 1) / g.k_split; g.slab_stride = (size_t)W * W;
     double t = time_gemm(g, 20); printf("dW split %d      %.3f ms %.1f TF\n", ns, t, fl / t / 1e9); }
   for (int div : {1, 2, 4, 8, 16}) {  // size sweep: fixed per-launch cost?
-    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P / div; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
+    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P / div; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
     if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; }
     double t = time_gemm(g, 40); printf("fwd plain I=P/%-2d  %.3f ms %.1f TF\n", div, t, fl / div / t / 1e9);
   }
 #ifdef SNERF_ABL_CLOCK
-  {  // steady-state shader clock under this kernel: >= 2 s of back-to-back launches, then read the stamps
-    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W;
+  {  // per-workgroup phase cycles of the split kernel (colsum doubles as the stamp buffer; the epilogue skips colsum under CLOCK)
+    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
+    if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; }
+    if (argc <= 5 || atoi(argv[5]) != 0) { g.bias = Wt; g.act = ACT_SIN; g.w0 = 1.f; }
     unsigned long long* dbg; const int nb = (P / 128) * (W / 128);
     CK(hipMalloc(&dbg, (size_t)nb * 64)); CK(hipMemset(dbg, 0, (size_t)nb * 64));
-    time_gemm(g, 1800);
+    time_gemm(g, 300);
     g.colsum = (float*)dbg; g.ldcs = 4;
-    time_gemm(g, 50);
+    double t = time_gemm(g, 20);
     std::vector<unsigned long long> hs((size_t)nb * 8);
     CK(hipMemcpy(hs.data(), dbg, hs.size() * 8, hipMemcpyDeviceToHost));
-    std::vector<double> f, pro, mainl, epi; unsigned long long tmin = ~0ull, tmax = 0;
-    for (int i = 0; i < nb; ++i) if (hs[8 * i + 1] > 0) {
-      f.push_back((double)hs[8 * i] / (double)hs[8 * i + 1] * 0.1);
-      pro.push_back((double)hs[8 * i + 2]); mainl.push_back((double)(hs[8 * i] - hs[8 * i + 2])); epi.push_back((double)hs[8 * i + 3]);
-      tmin = std::min(tmin, hs[8 * i + 4]); tmax = std::max(tmax, hs[8 * i + 4]); }
-    auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
-    printf("in-kernel clock: median %.3f GHz over %zu workgroups\n", med(f), f.size());
-    { unsigned long long r0 = ~0ull, r1 = 0; double sum = 0; int cnt[9] = {0};
-      for (int i = 0; i < nb; ++i) { r0 = std::min(r0, hs[8 * i + 5]); r1 = std::max(r1, hs[8 * i + 6]); sum += (double)(hs[8 * i + 6] - hs[8 * i + 5]); cnt[hs[8 * i + 7] % 9]++; }
-      printf("last launch: span %.1f us, sum of WG lifetimes %.1f us -> mean resident WGs per CU %.2f; WGs per XCC id+1:", (r1 - r0) * 0.01, sum * 0.01, sum / (double)(r1 - r0) / 256.0);
-      for (int i = 0; i < 9; ++i) printf(" %d", cnt[i]); printf("\n");
-      for (int x = 1; x <= 8; ++x) { unsigned long long a0 = ~0ull, a1 = 0; double sm = 0; int n = 0;
-        for (int i = 0; i < nb; ++i) if ((int)hs[8 * i + 7] == x) { a0 = std::min(a0, hs[8 * i + 5]); a1 = std::max(a1, hs[8 * i + 6]); sm += (double)(hs[8 * i + 6] - hs[8 * i + 5]); ++n; }
-        printf("  xcc %d: %d WGs, span %.1f us, mean resident WGs per CU %.2f, start offset vs global min %.1f us\n", x - 1, n, (a1 - a0) * 0.01, sm / (double)(a1 - a0) / 32.0, (a0 - r0) * 0.01); } }
-    printf("cycles per workgroup (median): prologue %.0f  main loop %.0f  epilogue(incl. store drain) %.0f; first->last WG start %llu cycles\n",
-           med(pro), med(mainl), med(epi), tmax - tmin);
+    auto med = [&](int f) { std::vector<double> v; for (int i = 0; i < nb; ++i) if (hs[8 * i + 6] > 0) v.push_back((double)hs[8 * i + f]); std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+    printf("fwd sin %.3f ms; median cycles per workgroup: prologue %.0f  k-loop %.0f  epilogue issue %.0f  store drain (vmcnt 0) %.0f  total %.0f\n", t, med(0), med(1), med(2), med(3), med(6));
+    unsigned long long r0 = ~0ull, r1 = 0; double sum = 0;
+    for (int i = 0; i < nb; ++i) if (hs[8 * i + 6] > 0) { r0 = std::min(r0, hs[8 * i + 4]); r1 = std::max(r1, hs[8 * i + 5]); sum += (double)(hs[8 * i + 5] - hs[8 * i + 4]); }
+    printf("launch span %.1f us; mean resident workgroups per CU %.2f; clock %.2f GHz\n", (r1 - r0) * 0.01, sum / (double)(r1 - r0) / 256.0, med(6) / ((sum / nb) * 10.0));
   }
 #endif
   return 0;
