@@ -99,6 +99,42 @@ __device__ __forceinline__ float sin_signcos(float x, bool* cos_neg) {
   return odd ? -s : s;
 }
 
+// Four at once: the large-argument test is ONE wave-uniform branch (ballot), so the common path is straight-line code
+// whose four dependency chains the scheduler interleaves; per-element tests cost an exec-mask dance and a branch each
+// and serialise the chains.  Returns the four sines; bit c of *neg = cos(x_c) < 0.
+__device__ __forceinline__ float4 sin4_signcos(float4 x, unsigned* neg) {
+  const float m = fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w)));
+  float4 s;
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(m <= 30000.f)) == 0ull, 1)) {
+    float xs[4] = {x.x, x.y, x.z, x.w}, out[4];
+    unsigned bits = 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float kf = rintf(xs[c] * 0.31830988618379067154f);
+      float r = fmaf(kf, -3.140625f, xs[c]);
+      r = fmaf(kf, -9.67502593994140625e-4f, r);
+      r = fmaf(kf, -1.509958025280866e-07f, r);
+      r = fmaf(kf, 3.4302490200117638e-15f, r);
+      const float r2 = r * r;
+      float p = fmaf(r2, -2.5028294103890403e-08f, 2.755689592959243e-06f);
+      p = fmaf(p, r2, -0.00019841265748254955f);
+      p = fmaf(p, r2, 0.008333333767950535f);
+      p = fmaf(p, r2, -0.1666666716337204f);
+      const float sv = fmaf(r * r2, p, r);
+      const unsigned odd = (unsigned)(int)kf & 1u;
+      out[c] = __uint_as_float(__float_as_uint(sv) ^ (odd << 31));
+      bits |= (odd ^ (fabsf(r) > 1.57079637f ? 1u : 0u)) << c;
+    }
+    s = make_float4(out[0], out[1], out[2], out[3]);
+    *neg = bits;
+  } else {
+    bool n0, n1, n2, n3;
+    s.x = sin_signcos(x.x, &n0); s.y = sin_signcos(x.y, &n1); s.z = sin_signcos(x.z, &n2); s.w = sin_signcos(x.w, &n3);
+    *neg = (n0 ? 1u : 0u) | (n1 ? 2u : 0u) | (n2 ? 4u : 0u) | (n3 ? 8u : 0u);
+  }
+  return s;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

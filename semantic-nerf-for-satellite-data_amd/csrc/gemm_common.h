@@ -38,6 +38,15 @@ struct KArgs {
   int tiles_i, tiles_j;
 };
 
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ size_t uniform_sz(size_t v) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((size_t)hi << 32) | lo;
+}
+// |cos| from the stored sine: hardware square root (1 ulp) of the once-rounded 1 - h^2; sqrtf() would expand into the
+// ~15-instruction correctly rounded sequence, four times per lane and pass
+__device__ __forceinline__ float cos_from_sin(float h) { return __builtin_amdgcn_sqrtf(fmaxf(fmaf(-h, h, 1.f), 0.f)); }
+
 // ---- operand scaling of the fp16-plane mode --------------------------------------------------------------------
 constexpr int MAX_SLOTS = 64;   // |max| of a tensor = max over 64 slots of float bits (spreads the atomics)
 // power of two s with max * s in [2^13, 2^14) (fp16 overflows at 2^16), clamped to 2^+-60; 1 for an empty / non-finite max
@@ -194,11 +203,9 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
         const size_t off = (size_t)row * p.ldc + col;
         if (p.act == ACT_SIN && p.C2 == nullptr) {
           // sin and the sign of cos only (the derivative is rebuilt from h in the backward epilogue)
-          bool n0, n1, n2, n3;
-          v.x = sin_signcos(p.w0 * v.x, &n0); v.y = sin_signcos(p.w0 * v.y, &n1);
-          v.z = sin_signcos(p.w0 * v.z, &n2); v.w = sin_signcos(p.w0 * v.w, &n3);
-          if (WJ == 64 && p.C2s != nullptr)
-            sbits |= ((n0 ? 1u : 0u) | (n1 ? 2u : 0u) | (n2 ? 4u : 0u) | (n3 ? 8u : 0u)) << (4 * ps);
+          unsigned nb;
+          v = sin4_signcos(make_float4(p.w0 * v.x, p.w0 * v.y, p.w0 * v.z, p.w0 * v.w), &nb);
+          if (WJ == 64 && p.C2s != nullptr) sbits |= nb << (4 * ps);
         } else if (p.act == ACT_SIN) {   // diagnostic form: w0*cos stored as floats (SNERF_DERIV=float)
           float4 cn;
           sincos_acc(p.w0 * v.x, &v.x, &cn.x);
@@ -219,8 +226,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
           else if (p.aux_mode == AUX_SINREC) {
             // x = h = sin(w0 z): |cos| = sqrt(1 - h^2) (one rounding: fma), sign from the stored bit
             const unsigned nib = sword >> (4 * ps);
-            const float dx = p.w0 * sqrtf(fmaxf(fmaf(-x.x, x.x, 1.f), 0.f)), dy = p.w0 * sqrtf(fmaxf(fmaf(-x.y, x.y, 1.f), 0.f));
-            const float dz = p.w0 * sqrtf(fmaxf(fmaf(-x.z, x.z, 1.f), 0.f)), dw = p.w0 * sqrtf(fmaxf(fmaf(-x.w, x.w, 1.f), 0.f));
+            const float dx = p.w0 * cos_from_sin(x.x), dy = p.w0 * cos_from_sin(x.y);
+            const float dz = p.w0 * cos_from_sin(x.z), dw = p.w0 * cos_from_sin(x.w);
             v.x *= (nib & 1u) ? -dx : dx; v.y *= (nib & 2u) ? -dy : dy;
             v.z *= (nib & 4u) ? -dz : dz; v.w *= (nib & 8u) ? -dw : dw;
           }
@@ -267,7 +274,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
 // strip, and the eight row stores of a block are issued back to back.  With branches in the loop the compiler has to
 // fall back to s_waitcnt vmcnt(0) after every load / before every LDS read: each of the 16 stores and aux loads of a
 // wave then cost a full memory round trip (measured: 24-32 k of a workgroup's 85-90 k cycles).
-typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void buf_store4(srd_t s, unsigned off, float4 v) {
   u32x4s d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
   __builtin_amdgcn_raw_buffer_store_b128(d, s, off, 0, 0);
@@ -284,8 +290,11 @@ __device__ __forceinline__ void gemm_epilogue_fast(const f32x16 (&acc)[MI][NJ], 
   const int col = col0 + c4;
   const bool col_ok = col < p.J;
   // descriptors based at the wave tile's first element; offsets are tile-relative (< 2^31 by launch_gemm's span check)
-  const srd_t srdC = make_srd(C + (size_t)row0 * p.ldc + col0, 0xFFFFFFE0u);
-  const srd_t srdAux = make_srd(AUX != AUX_NONE ? p.aux + (size_t)row0 * p.ldaux + col0 : nullptr, AUX != AUX_NONE ? 0xFFFFFFE0u : 0u);
+  // row0 / col0 derive from the wave id: wave-uniform, but only readfirstlane tells the compiler so -- a descriptor it
+  // believes divergent is wrapped in a readfirstlane "waterfall" loop around every access
+  const size_t offC = uniform_sz((size_t)row0 * p.ldc + col0), offA = uniform_sz((size_t)row0 * p.ldaux + col0);
+  const srd_t srdC = make_srd(C + offC, 0xFFFFFFE0u);
+  const srd_t srdAux = make_srd(AUX != AUX_NONE ? p.aux + offA : nullptr, AUX != AUX_NONE ? 0xFFFFFFE0u : 0u);
   float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias != nullptr && col_ok) bj = *reinterpret_cast<const float4*>(p.bias + col);
   const bool signs_out = ACT == ACT_SIN && p.C2s != nullptr;
@@ -319,18 +328,17 @@ __device__ __forceinline__ void gemm_epilogue_fast(const f32x16 (&acc)[MI][NJ], 
       float4 w = *reinterpret_cast<const float4*>(&strip[(rrow + RPP * ps) * EP + c4]);
       w.x += bj.x; w.y += bj.y; w.z += bj.z; w.w += bj.w;
       if (ACT == ACT_SIN) {
-        bool n0, n1, n2, n3;
-        w.x = sin_signcos(p.w0 * w.x, &n0); w.y = sin_signcos(p.w0 * w.y, &n1);
-        w.z = sin_signcos(p.w0 * w.z, &n2); w.w = sin_signcos(p.w0 * w.w, &n3);
-        sbits |= ((n0 ? 1u : 0u) | (n1 ? 2u : 0u) | (n2 ? 4u : 0u) | (n3 ? 8u : 0u)) << (4 * ps);
+        unsigned nb;
+        w = sin4_signcos(make_float4(p.w0 * w.x, p.w0 * w.y, p.w0 * w.z, p.w0 * w.w), &nb);
+        sbits |= nb << (4 * ps);
       } else if (ACT == ACT_RELU) {
         w.x = fmaxf(w.x, 0.f); w.y = fmaxf(w.y, 0.f); w.z = fmaxf(w.z, 0.f); w.w = fmaxf(w.w, 0.f);
       }
       if (AUX == AUX_SINREC) {
         const float4 x = ax[ps];
         const unsigned nib = sword >> (4 * ps);
-        const float dx = p.w0 * sqrtf(fmaxf(fmaf(-x.x, x.x, 1.f), 0.f)), dy = p.w0 * sqrtf(fmaxf(fmaf(-x.y, x.y, 1.f), 0.f));
-        const float dz = p.w0 * sqrtf(fmaxf(fmaf(-x.z, x.z, 1.f), 0.f)), dw = p.w0 * sqrtf(fmaxf(fmaf(-x.w, x.w, 1.f), 0.f));
+        const float dx = p.w0 * cos_from_sin(x.x), dy = p.w0 * cos_from_sin(x.y);
+        const float dz = p.w0 * cos_from_sin(x.z), dw = p.w0 * cos_from_sin(x.w);
         w.x *= (nib & 1u) ? -dx : dx; w.y *= (nib & 2u) ? -dy : dy;
         w.z *= (nib & 4u) ? -dz : dz; w.w *= (nib & 8u) ? -dw : dw;
       } else if (AUX == AUX_RELU_MASK) {
