@@ -226,7 +226,7 @@ def main():
         achieved = fp32_eq * mult
         # HBM bytes per launch of that kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
         # the MI355X guide), measured on this exact workload: profiles/r01/pmc_hbm_traffic.md
-        traffic = 1.352e9 if (mode == "f16x2" and args.rays == 4096 and args.samples == 64) else None
+        traffic = 1.357e9 if (mode == "f16x2" and args.rays == 4096 and args.samples == 64) else None
         line["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
             "kernel": (("snerf::gemm_x6_kernel<false,true,2,128,1> (two fp16 planes of power-of-two-scaled fp32 operands, hh + hl + lh = 3 x "

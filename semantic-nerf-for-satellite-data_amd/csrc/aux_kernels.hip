@@ -205,23 +205,42 @@ int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes
 
 // |max| of a rows x cols block (leading dimension ld) into 64 slots of float bits (atomicMax; order-independent, so
 // deterministic).  Slots must have been zeroed.  Used for tensors whose producer is not a GEMM epilogue.
-__global__ void absmax_kernel(const float* __restrict__ x, int rows, int cols, int ld, unsigned* __restrict__ slots) {
-  const size_t n = (size_t)rows * cols;
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int rows, int cols, int ld, unsigned* __restrict__ slots,
+                                                     int vec4) {
+  __shared__ float part[4];
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t r = i / cols;
-    m = fmaxf(m, fabsf(x[r * ld + (i - r * cols)]));
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  if (vec4) {   // contiguous and 16-byte aligned: float4 loads
+    const size_t n4 = (size_t)rows * cols / 4;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const float4 v = x4[i];
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  } else {
+    const size_t n = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+      const size_t r = i / cols;
+      m = fmaxf(m, fabsf(x[r * ld + (i - r * cols)]));
+    }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63), __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {   // one atomic per workgroup
+    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    if (m > 0.f) atomicMax(slots + (blockIdx.x & 63), __float_as_uint(m));
+  }
 }
 
 int launch_absmax(const float* x, int rows, int cols, int ld, unsigned* slots, hipStream_t st) {
   const size_t n = (size_t)rows * cols;
   if (n == 0) return 0;
-  const size_t want = (n + 255) / 256;
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(256), 0, st, x, rows, cols, ld, slots);
+  const int vec4 = (cols == ld && (cols & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
+  const size_t want = (n + 8191) / 8192;   // >= 32 elements per thread
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(want < 1024 ? (want ? want : 1) : 1024)), dim3(256), 0, st, x, rows, cols, ld,
+                     slots, vec4);
   SNERF_LAUNCH_CHECK();
   return 0;
 }
