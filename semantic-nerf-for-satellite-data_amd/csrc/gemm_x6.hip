@@ -61,6 +61,7 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4& hi, bf16x4& mid, 
 // 22 significant bits of the scaled value; with hh + hl + lh the dropped lo*lo term is 2^-22 relative -- below the
 // rounding of an fp32 GEMM.  Returned as bf16x4 bit patterns (the LDS image is format-agnostic 16-bit data).
 __device__ __forceinline__ void split2h(const float4 v, float scale, bf16x4& hi, bf16x4& lo) {
+#ifdef SNERF_ABL_CSPLIT   // plain C form (the compiler spends ~4.5 VALU per element on it)
   const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
   f16x4 h, l;
 #pragma unroll
@@ -70,6 +71,23 @@ __device__ __forceinline__ void split2h(const float4 v, float scale, bf16x4& hi,
   }
   hi = __builtin_bit_cast(bf16x4, h);
   lo = __builtin_bit_cast(bf16x4, l);
+#else
+  // two mixed-precision FMAs per element: hi = f16(x * s) and lo = f16(x * s - hi) (one rounding each; x * s is exact),
+  // written straight into the packed halves
+  unsigned h01, h23, l01, l23;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(v.x), "v"(scale));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v.y), "v"(scale));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(v.z), "v"(scale));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v.w), "v"(scale));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l01) : "v"(v.x), "v"(scale), "v"(h01));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v.y), "v"(scale), "v"(h01));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l23) : "v"(v.z), "v"(scale), "v"(h23));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v.w), "v"(scale), "v"(h23));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const u32x2 hh = {h01, h23}, ll = {l01, l23};
+  hi = __builtin_bit_cast(bf16x4, hh);
+  lo = __builtin_bit_cast(bf16x4, ll);
+#endif
 }
 
 // byte offset inside one plane
@@ -96,6 +114,21 @@ __device__ __forceinline__ void store_planes(const float4 (&v)[2], char* __restr
     if (NP > 1) *reinterpret_cast<bf16x4*>(op + T::PLANE_BYTES + o) = mid;
     if (NP > 2) *reinterpret_cast<bf16x4*>(op + 2 * T::PLANE_BYTES + o) = lo;
   }
+}
+
+// one float4 (the r-th of thread t) of an operand tile -> its planes in the LDS image
+template <bool IC, int NP, int BT, int FMT>
+__device__ __forceinline__ void store_planes_one(const float4 v, int r, char* __restrict__ op, int t, float scale) {
+  using T = TileCfg<BT>;
+  int il, kl;
+  tile_coord<BT, IC, T::NTH>(t, r, il, kl);
+  bf16x4 hi, mid, lo;
+  if (FMT == 1) split2h(v, scale, hi, mid);
+  else split3(v, hi, mid, lo);
+  const int o = IC ? ic_off<BT>(il, kl) : kc_off(il, kl);
+  *reinterpret_cast<bf16x4*>(op + o) = hi;
+  if (NP > 1) *reinterpret_cast<bf16x4*>(op + T::PLANE_BYTES + o) = mid;
+  if (NP > 2) *reinterpret_cast<bf16x4*>(op + 2 * T::PLANE_BYTES + o) = lo;
 }
 
 // MFMA operand fragment of one 32-row block (rows r0 .. r0+31 of the tile) from plane `pl`
@@ -125,8 +158,15 @@ __device__ __forceinline__ bf16x8 load_frag(const char* __restrict__ pl, int r0,
 // NP bf16 planes per operand: 3 = fp32-class (six products, the default); 2 = hi | mid with the three products
 // hh, hm, mh (~16 significant bits); 1 = plain bf16 operands, one product.
 // FMT 1 (NP = 2): fp16 planes, operands scaled by powers of two derived from their |max| slots, products hh + hl + lh.
-template <bool IC, bool BPL, int NP, int BT, int FMT = 0>
+// PP (BT = 256 only): ping-pong schedule.  The eight waves form two groups (rows 0-127 / 128-255 of the tile; one wave
+// of each group per SIMD) that run the same four-phase k-tile -- fragment reads + staging | MFMAs of block rows 0-1 |
+// fragment reads + staging + global loads | MFMAs of block rows 2-3 -- one workgroup barrier apart, so while one wave
+// of a SIMD issues its MFMAs back to back at raised priority the other does its LDS and VALU work.  Without it the two
+// waves of a SIMD (same workgroup, same barrier) read, compute and stage in lockstep.  (Measured: no gain over the lockstep
+// schedule -- see launch_x6 -- so it is an option, not the default.)
+template <bool IC, bool BPL, int NP, int BT, int FMT = 0, bool PP = false>
 __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6_kernel(const KArgs p) {
+  static_assert(!PP || BT == 256, "ping-pong needs the 8-wave tile");
   using T = TileCfg<BT>;
   constexpr int MI = T::MI, NJ = T::NJ, NTH = T::NTH;
   constexpr int PLANE_BYTES = T::PLANE_BYTES;
@@ -147,6 +187,7 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
     sa = scale_of_max(slots_max(p.amaxA, p.amaxA2, lane));
     sb = scale_of_max(slots_max(p.amaxB, nullptr, lane));
   }
+  const float sa_scale = sa, sb_scale = sb;
   __builtin_amdgcn_s_setprio(2);  // non-MFMA phases at raised priority (see gemm.hip)
   int ti, tj;
   int kBeg = 0, kEnd = p.K;
@@ -300,6 +341,92 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
     __syncthreads();
   };
 
+  // ---- ping-pong k-tile (PP) ------------------------------------------------------------------------------------
+  // LDS ordering: every phase that touches LDS ends with s_waitcnt lgkmcnt(0) before the barrier, so reads and writes
+  // of a phase are complete when any wave passes it.  Tile kt+1 is written (stage (kt+1)&1) in the memory phases of
+  // iteration kt -- the last of them, group 1's second, one barrier before group 0 first reads it; stage kt&1 is
+  // rewritten (tile kt+2) from group 0's first memory phase of iteration kt+1, one barrier after group 1's last read.
+  auto pp_barrier_mem = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto pp_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto ktile_pp = [&](int kt, Tile& r) {
+    const char* sa = lds + (kt & 1) * STAGE_BYTES;
+    const char* sb = sa + OPERAND_BYTES;
+    char* dst = lds + ((kt + 1) & 1) * STAGE_BYTES;
+    bf16x8 b[NP][NJ], a[2][NP];
+    auto block = [&](int mi, int nj) {
+      const bf16x8 (&am)[NP] = a[mi & 1];
+      f32x16 c = acc[mi][nj];
+      if constexpr (FMT == 1) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, am[0]), al = __builtin_bit_cast(f16x8, am[1]);
+        const f16x8 bh = __builtin_bit_cast(f16x8, b[0][nj]), bl = __builtin_bit_cast(f16x8, b[1][nj]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+      } else {
+        if constexpr (NP > 2) {
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], b[1][nj], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], b[2][nj], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[2], b[0][nj], c, 0, 0, 0);
+        }
+        if constexpr (NP > 1) {
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], b[1][nj], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], b[0][nj], c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], b[0][nj], c, 0, 0, 0);
+      }
+      acc[mi][nj] = c;
+    };
+    auto load_a2 = [&](int mi0) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) a[q][pl] = load_frag<IC, BT>(sa + pl * PLANE_BYTES, wi0 + 32 * (mi0 + q), lane);
+    };
+    // -- memory phase 0: B fragments, A fragments of block rows 0-1; first float4 of tile kt+1's A
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) b[pl][nj] = load_frag<IC, BT>(sb + pl * PLANE_BYTES, wj0 + 32 * nj, lane);
+    load_a2(0);
+    store_planes_one<IC, NP, BT, FMT>(r.ra[0], 0, dst, t, sa_scale);
+    pp_barrier_mem();
+    // -- MFMA phase 0
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) block(mi, nj);
+    __builtin_amdgcn_s_setprio(0);
+    pp_barrier();
+    // -- memory phase 1: A fragments of block rows 2-3; rest of tile kt+1; request tile kt+3
+    load_a2(2);
+    store_planes_one<IC, NP, BT, FMT>(r.ra[1], 1, dst, t, sa_scale);
+    if (BPL) {
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x4*>(dst + OPERAND_BYTES + pl * PLANE_BYTES + 16 * t) = r.rbp[pl];
+    } else {
+      store_planes<IC, NP, BT, FMT>(r.rb, dst + OPERAND_BYTES, t, sb_scale);
+    }
+    fetch(kBeg + (kt + 3) * BK, r);
+    pp_barrier_mem();
+    // -- MFMA phase 1
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mi = 2; mi < 4; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) block(mi, nj);
+    __builtin_amdgcn_s_setprio(0);
+    pp_barrier();
+  };
+
   Tile r0, r1;
   fetch(kBeg, r0);
   store(r0, lds);
@@ -312,9 +439,19 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
 #endif
   __builtin_amdgcn_s_setprio(0);
   // k-tiles in pairs (an odd count runs one extra tile of zeros: fetches beyond kEnd return zeros)
-  for (int kt = 0; kt < nkt; kt += 2) {
-    ktile(kt, r0);
-    ktile(kt + 1, r1);
+  if constexpr (PP) {
+    const int grp = wave >> 2;               // 0: tile rows 0-127, 1: rows 128-255 (one wave of each per SIMD)
+    if (grp == 1) pp_barrier();              // group 1 runs one phase behind
+    for (int kt = 0; kt < nkt; kt += 2) {
+      ktile_pp(kt, r0);
+      ktile_pp(kt + 1, r1);
+    }
+    if (grp == 0) pp_barrier();              // same barrier count for both groups
+  } else {
+    for (int kt = 0; kt < nkt; kt += 2) {
+      ktile(kt, r0);
+      ktile(kt + 1, r1);
+    }
   }
 #ifdef SNERF_ABL_CLOCK
   const unsigned long long clk2 = __builtin_amdgcn_s_memtime();
@@ -342,19 +479,24 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
 #endif
 }
 
-template <int NP, int BT, int FMT = 0>
+template <int NP, int BT, int FMT = 0, bool PP = false>
 static void launch_np(bool ic, bool b_planes, const KArgs& p, dim3 grid, hipStream_t stream) {
   const dim3 block(TileCfg<BT>::NTH);
-  if (ic) hipLaunchKernelGGL((gemm_x6_kernel<true, false, NP, BT, FMT>), grid, block, 0, stream, p);
-  else if (b_planes) hipLaunchKernelGGL((gemm_x6_kernel<false, true, NP, BT, FMT>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((gemm_x6_kernel<false, false, NP, BT, FMT>), grid, block, 0, stream, p);
+  if (ic) hipLaunchKernelGGL((gemm_x6_kernel<true, false, NP, BT, FMT, PP>), grid, block, 0, stream, p);
+  else if (b_planes) hipLaunchKernelGGL((gemm_x6_kernel<false, true, NP, BT, FMT, PP>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((gemm_x6_kernel<false, false, NP, BT, FMT, PP>), grid, block, 0, stream, p);
 }
 
 // tile: 128 or 256 (p.tiles_i / p.tiles_j and the grid must have been computed for it); fmt 1 = fp16 planes (planes = 2)
 void launch_x6(bool ic, bool b_planes, int planes, int fmt, int tile, const KArgs& p, dim3 grid, hipStream_t stream) {
   if (fmt == 1) {
-    if (tile == 256) launch_np<2, 256, 1>(ic, b_planes, p, grid, stream);
-    else launch_np<2, 128, 1>(ic, b_planes, p, grid, stream);
+    if (tile == 256) {
+      // measured equal within noise (dW 0.359 vs 0.353 ms, K-contiguous 0.491 vs 0.485 ms): the loop is not bound by the
+      // waves' phase alignment; the lockstep schedule stays the default, SNERF_X6_PP=1 selects the ping-pong one
+      static const bool pp = getenv("SNERF_X6_PP") && atoi(getenv("SNERF_X6_PP")) == 1;
+      if (pp) launch_np<2, 256, 1, true>(ic, b_planes, p, grid, stream);
+      else launch_np<2, 256, 1>(ic, b_planes, p, grid, stream);
+    } else launch_np<2, 128, 1>(ic, b_planes, p, grid, stream);
     return;
   }
   if (tile == 256) {
