@@ -79,7 +79,8 @@ def test_gemm_fp16_planes_scaled(a_ic, b_ic, I, J, K, amag, bmag):
 def test_gemm_fp16_planes_pingpong_tile(a_ic, b_ic, I, J, K):
     """the 256 x 256 tile with the two-group ping-pong schedule (forced for K-contiguous operands too), ragged edges,
     odd k-tile counts and a single k-tile"""
-    _fp16_planes_case(a_ic, b_ic, I, J, K, 1.0, 0.05, 4 | 128 | 32)
+    _fp16_planes_case(a_ic, b_ic, I, J, K, 1.0, 0.05, 4 | 128 | 32 | 256)   # 256: ping-pong schedule
+    _fp16_planes_case(a_ic, b_ic, I, J, K, 1.0, 0.05, 4 | 128 | 32)         # lockstep schedule on the same tile
 
 
 def _fp16_planes_case(a_ic, b_ic, I, J, K, amag, bmag, flags):
