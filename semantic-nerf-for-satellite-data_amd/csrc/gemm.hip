@@ -23,7 +23,7 @@
 
 namespace snerf {
 
-void launch_x6(bool ic, bool b_planes, int planes, int fmt, int tile, const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip
+void launch_x6(bool ic, bool b_planes, int planes, int fmt, int tile, int pp, const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip
 
 template <int BI, bool IC>
 struct Tile {
@@ -271,7 +271,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
       p.tiles_i = (g.I + 255) / 256; p.tiles_j = (g.J + 255) / 256;
       grid.x = p.tiles_i * p.tiles_j;
     }
-    launch_x6(A_IC, g.Bpl != nullptr && !A_IC, g.planes, g.fmt, tile, p, grid, stream);
+    launch_x6(A_IC, g.Bpl != nullptr && !A_IC, g.planes, g.fmt, tile, g.pp, p, grid, stream);
   }
   else hipLaunchKernelGGL((gemm_kernel<BI, BJ, WI, WJ, A_IC, B_IC>), grid, dim3(NT), 0, stream, p);
   SNERF_LAUNCH_CHECK();

@@ -488,12 +488,13 @@ static void launch_np(bool ic, bool b_planes, const KArgs& p, dim3 grid, hipStre
 }
 
 // tile: 128 or 256 (p.tiles_i / p.tiles_j and the grid must have been computed for it); fmt 1 = fp16 planes (planes = 2)
-void launch_x6(bool ic, bool b_planes, int planes, int fmt, int tile, const KArgs& p, dim3 grid, hipStream_t stream) {
+void launch_x6(bool ic, bool b_planes, int planes, int fmt, int tile, int pp_arg, const KArgs& p, dim3 grid, hipStream_t stream) {
   if (fmt == 1) {
     if (tile == 256) {
       // measured equal within noise (dW 0.359 vs 0.353 ms, K-contiguous 0.491 vs 0.485 ms): the loop is not bound by the
       // waves' phase alignment; the lockstep schedule stays the default, SNERF_X6_PP=1 selects the ping-pong one
-      static const bool pp = getenv("SNERF_X6_PP") && atoi(getenv("SNERF_X6_PP")) == 1;
+      static const bool pp_env = getenv("SNERF_X6_PP") && atoi(getenv("SNERF_X6_PP")) == 1;
+      const bool pp = pp_arg < 0 ? pp_env : pp_arg != 0;
       if (pp) launch_np<2, 256, 1, true>(ic, b_planes, p, grid, stream);
       else launch_np<2, 256, 1>(ic, b_planes, p, grid, stream);
     } else launch_np<2, 128, 1>(ic, b_planes, p, grid, stream);
