@@ -35,6 +35,16 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(Wt, h.data(), (size_t)W * W * 4, hipMemcpyHostToDevice));
   unsigned short* Bplanes; CK(hipMalloc(&Bplanes, (size_t)3 * W * W * 2 + 4096)); CK(hipMemset(Bplanes, 0, (size_t)3 * W * W * 2));
   const double fl = 2.0 * P * W * W;
+  if (argc > 6 && atoi(argv[6]) >= 1) {   // counter runs: ONE kernel configuration only (1: fwd plain, 2: dW split 64)
+    GemmArgs g;
+    if (atoi(argv[6]) == 1) { g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W;
+      if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; } }
+    else { g.A = X; g.lda = W; g.a_ic = true; g.B = Y2; g.ldb = W; g.b_ic = true; g.I = W; g.J = W; g.K = P; g.C = dW; g.ldc = W;
+      g.k_split = ((P + 63) / 64 + 31) / 32 * 32; g.n_split = (P + g.k_split - 1) / g.k_split; g.slab_stride = (size_t)W * W; }
+    g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
+    double t = time_gemm(g, 12); printf("only-mode %d: %.3f ms\n", atoi(argv[6]), t);
+    return 0;
+  }
   { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
     time_gemm(g, 400); }  // clock / power state warm-up
   { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
