@@ -242,7 +242,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
   p.bias = g.bias; p.aux = g.aux; p.colsum = g.colsum;
   p.C2s = g.C2s; p.auxs = g.aux_sign; p.sign_col0 = g.aux_sign ? g.sign_col0 : 0;
   p.sign_groups = ((g.aux_sign ? g.ldaux : g.ldc) + 63) / 64;
-  static const unsigned epi_mask = getenv("SNERF_FAST_EPI") ? (unsigned)atoi(getenv("SNERF_FAST_EPI")) : 29u;  // default: all but the SIREN forward kind (measured slower: 43.3 vs 39.6 ms per step); env for A/B
+  static const unsigned epi_mask = getenv("SNERF_FAST_EPI") ? (unsigned)atoi(getenv("SNERF_FAST_EPI")) : 31u;  // all kinds; env for A/B of single kinds (bit 0 plain, 1 sin, 2 relu, 3 sinrec, 4 relu mask)
   p.epi_mask = epi_mask;
   p.amaxA = g.a_max; p.amaxA2 = g.A2 ? g.a2_max : nullptr; p.amaxB = g.b_max; p.cmax = g.c_max;
   p.lda = g.lda; p.lda2 = g.A2 ? g.lda2 : g.lda; p.Ka = g.A2 ? g.Ka : 0x7fffffff;

@@ -279,7 +279,7 @@ __device__ __forceinline__ void buf_store4(srd_t s, unsigned off, float4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(d, s, off, 0, 0);
 }
 
-template <int MI, int NJ, int ACT, int AUX>
+template <int MI, int NJ, int ACT, int AUX, bool COLSUM>
 __device__ __forceinline__ void gemm_epilogue_fast(const f32x16 (&acc)[MI][NJ], float* __restrict__ lds, int wave, int lane,
                                                    int row0, int col0, const KArgs& p, float* __restrict__ C, float acc_scale) {
   constexpr int WJ = 64, EP = WJ + 4, EPI = 32 * EP, LPR = 16, RPP = 4, NPASS = 8;
@@ -345,13 +345,16 @@ __device__ __forceinline__ void gemm_epilogue_fast(const f32x16 (&acc)[MI][NJ], 
         const float4 x = ax[ps];
         w.x = x.x > 0.f ? w.x : 0.f; w.y = x.y > 0.f ? w.y : 0.f; w.z = x.z > 0.f ? w.z : 0.f; w.w = x.w > 0.f ? w.w : 0.f;
       }
-      if (!ok) w = make_float4(0.f, 0.f, 0.f, 0.f);    // keeps column sums / max clean; the store is rejected anyway
-      cs.x += w.x; cs.y += w.y; cs.z += w.z; cs.w += w.w;
-      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(w.x), fabsf(w.y))), fmaxf(fabsf(w.z), fabsf(w.w)));
+      if (COLSUM) {   // out-of-range rows must not enter the column sums (the store itself is rejected by the descriptor)
+        if (!ok) w = make_float4(0.f, 0.f, 0.f, 0.f);
+        cs.x += w.x; cs.y += w.y; cs.z += w.z; cs.w += w.w;
+      }
+      const float m4 = fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w)));
+      vmax = fmaxf(vmax, ok ? m4 : 0.f);
       buf_store4(srdC, ok ? ((unsigned)(32 * mi + rrow + RPP * ps) * (unsigned)p.ldc + (unsigned)c4) * 4u : OOB, w);
     }
     if (signs_out) __builtin_amdgcn_raw_buffer_store_b32(sbits, srdS, (col_ok && rbase < p.I) ? (unsigned)(sidx * 4) : OOB, 0, 0);
-    if (p.colsum != nullptr) {   // wave-uniform
+    if (COLSUM && p.colsum != nullptr) {   // wave-uniform
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1) {
         cs.x += __shfl_xor(cs.x, o, 64); cs.y += __shfl_xor(cs.y, o, 64);
@@ -376,13 +379,15 @@ __device__ __forceinline__ void gemm_epilogue_dispatch(const f32x16 (&acc)[MI][N
   if constexpr (WJ == 64 && NJ == 2) {
 #ifndef SNERF_ABL_OLDEPI
     const bool plain_store = p.C2 == nullptr && ((size_t)(MI * 32) * (size_t)(p.ldc > p.ldaux ? p.ldc : p.ldaux) * 4u < 0x7FFFFFFFu);
-    if (plain_store && p.aux_mode == AUX_NONE) {
-      if (p.act == ACT_NONE && (p.epi_mask & 1u)) return gemm_epilogue_fast<MI, NJ, ACT_NONE, AUX_NONE>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
-      if (p.act == ACT_SIN && (p.epi_mask & 2u)) return gemm_epilogue_fast<MI, NJ, ACT_SIN, AUX_NONE>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
-      if (p.act == ACT_RELU && (p.epi_mask & 4u)) return gemm_epilogue_fast<MI, NJ, ACT_RELU, AUX_NONE>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+    if (plain_store && p.aux_mode == AUX_NONE && p.colsum == nullptr) {
+      if (p.act == ACT_NONE && (p.epi_mask & 1u)) return gemm_epilogue_fast<MI, NJ, ACT_NONE, AUX_NONE, false>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+      if (p.act == ACT_SIN && (p.epi_mask & 2u)) return gemm_epilogue_fast<MI, NJ, ACT_SIN, AUX_NONE, false>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+      if (p.act == ACT_RELU && (p.epi_mask & 4u)) return gemm_epilogue_fast<MI, NJ, ACT_RELU, AUX_NONE, false>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+    } else if (plain_store && p.aux_mode == AUX_NONE && p.act == ACT_NONE) {   // plain store + bias-gradient column sums
+      if (p.epi_mask & 1u) return gemm_epilogue_fast<MI, NJ, ACT_NONE, AUX_NONE, true>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
     } else if (plain_store && p.act == ACT_NONE) {
-      if (p.aux_mode == AUX_SINREC && (p.epi_mask & 8u)) return gemm_epilogue_fast<MI, NJ, ACT_NONE, AUX_SINREC>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
-      if (p.aux_mode == AUX_RELU_MASK && (p.epi_mask & 16u)) return gemm_epilogue_fast<MI, NJ, ACT_NONE, AUX_RELU_MASK>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+      if (p.aux_mode == AUX_SINREC && (p.epi_mask & 8u)) return gemm_epilogue_fast<MI, NJ, ACT_NONE, AUX_SINREC, true>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
+      if (p.aux_mode == AUX_RELU_MASK && (p.epi_mask & 16u)) return gemm_epilogue_fast<MI, NJ, ACT_NONE, AUX_RELU_MASK, true>(acc, lds, wave, lane, row0, col0, p, C, acc_scale);
     }
 #endif
   }
