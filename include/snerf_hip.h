@@ -156,7 +156,9 @@ size_t snerf_workspace_bytes(const SnerfDesc* desc);
 
 /* ---- parameter packing ------------------------------------------------------------------------- */
 /* Gather the state_dict tensors into the padded, MFMA-friendly packed layout (DESIGN.md "Data layout").
- * Replaces nothing in the reference (torch.nn.Linear owns its layout there); run once per optimiser step. */
+ * Replaces nothing in the reference (torch.nn.Linear owns its layout there); run once per optimiser step.
+ * The pre-split weight planes inside the buffer follow desc->flags' arithmetic (bf16 planes, or fp16 planes with each
+ * matrix's |max| slots under SNERF_FLAG_F16X2): pack, forward and backward must use the same arithmetic flags. */
 int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* packed, void* stream);
 /* Scatter packed gradients back into tensors shaped like the parameters (overwrite, or add if accumulate). */
 int snerf_unpack_grads(const SnerfDesc* desc, const float* packed_grads, const SnerfParams* grads,
