@@ -309,19 +309,31 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
       c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], b[0][nj], c, 0, 0, 0);
       acc[mi][nj] = c;
     };
+#ifdef SNERF_ABL_PRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       if (mi == MI / 2) {
+#ifdef SNERF_ABL_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #if defined(SNERF_ABL_NOLDSSTORE)
         for (int q = 0; q < 2; ++q) { asm volatile("" :: "v"(r.ra[q].x), "v"(r.ra[q].y), "v"(r.ra[q].z), "v"(r.ra[q].w)); }
 #elif !defined(SNERF_ABL_NOGLOAD)
         store(r, dst);
+#endif
+#ifdef SNERF_ABL_PRIO
+        __builtin_amdgcn_s_setprio(1);
 #endif
       }
 #pragma unroll
       for (int nj = 0; nj < NJ; ++nj) block(mi, nj);
       if (mi + 2 < MI) load_a(mi + 2);
     }
+#ifdef SNERF_ABL_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #if !defined(SNERF_ABL_NOGLOAD) && !defined(SNERF_ABL_NOVMEM)
     fetch(kBeg + (kt + 3) * BK, r);
 #endif
