@@ -226,10 +226,10 @@ def main():
         achieved = fp32_eq * mult
         # HBM bytes per launch of that kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
         # the MI355X guide), measured on this exact workload: profiles/r01/pmc_hbm_traffic.md
-        traffic = 1.357e9 if (mode == "f16x2" and args.rays == 4096 and args.samples == 64) else None
+        traffic = 1.359e9 if (mode == "f16x2" and args.rays == 4096 and args.samples == 64) else None
         line["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "kernel": (("snerf::gemm_x6_kernel<false,true,2,128,1> (two fp16 planes of power-of-two-scaled fp32 operands, hh + hl + lh = 3 x "
+            "kernel": (("snerf::gemm_x6_kernel<false,true,2,128,1,false> (two fp16 planes of power-of-two-scaled fp32 operands, hh + hl + lh = 3 x "
                         "v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulate; forward X.W^T and dX launches)" if mode == "f16x2" else
                         "snerf::gemm_x6_kernel<false,true,NP,128> (split-bf16: NP bf16 planes per fp32 operand, 6 / 3 / 1 x v_mfma_f32_32x32x16_bf16 per "
                         "32x32x16 block for NP = 3 / 2 / 1, fp32 accumulate; forward X.W^T and dX launches)") if x6 else
