@@ -182,7 +182,8 @@ def main():
             _lib.check(L.snerf_profile_end(C.byref(prof)), "snerf_profile_end")
         finally:
             _rend.OVERLAP_SC_PASS = saved
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    gloo = world > 1 and torch.distributed.get_backend() == "gloo"   # rehearsal rigs; RCCL reduces on the device
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else device)
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())

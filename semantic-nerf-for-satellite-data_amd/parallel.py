@@ -22,13 +22,19 @@ def init_distributed(backend: str = None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
+    if use_cuda and local >= torch.cuda.device_count():
+        # rehearsal rigs only (several gloo ranks sharing one card): production launches have one GPU per rank
+        if (backend or os.environ.get("SNERF_DIST_BACKEND")) != "gloo":
+            raise RuntimeError(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
+        local = local % torch.cuda.device_count()
     device = torch.device(f"cuda:{local}") if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=ws)
+        backend = backend or os.environ.get("SNERF_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+        dist.init_process_group(backend, rank=rank, world_size=ws)
     return rank, ws, device
 
 
