@@ -16,6 +16,9 @@ from ..models.rs_semantic import inference as rs_semantic_inference
 
 # main and solar-correction passes on two HIP streams (set SNERF_OVERLAP_SC=0 to serialise them)
 OVERLAP_SC_PASS = os.environ.get("SNERF_OVERLAP_SC", "1") != "0"
+if OVERLAP_SC_PASS and hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    # the two passes deliberately run (and back-propagate) on two streams; autograd synchronises the accumulation itself
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
 _SIDE_STREAMS = {}
 
 

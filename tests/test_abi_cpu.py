@@ -54,6 +54,13 @@ def test_host_only_sizes_and_errors():
     bad = ModelSpec(fc_units=520).desc(16, 8)
     assert L.snerf_packed_floats(C.byref(bad)) == 0
     assert b"fc_units" in L.snerf_last_error()
+    # arithmetic flags are exclusive: fp16 planes with any of the bf16 / fp32-instruction flags is refused
+    for other in (_lib.FLAG_FP32_MFMA, _lib.FLAG_BF16, _lib.FLAG_BF16X3, _lib.FLAG_BWD_BF16X3):
+        bad = ModelSpec(mfma="split3").desc(16, 8, _lib.FLAG_F16X2 | other)
+        assert L.snerf_workspace_bytes(C.byref(bad)) == 0
+        assert b"SNERF_FLAG_F16X2" in L.snerf_last_error()
+    bad = ModelSpec(mfma="split3").desc(16, 8, _lib.FLAG_FP32_MFMA | _lib.FLAG_BF16)
+    assert L.snerf_workspace_bytes(C.byref(bad)) == 0
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -332,3 +332,58 @@ def test_lean_inference_equals_batched_inference(tmp_path):
     raw = open(fp, "rb").read()
     head, body = raw.split(b"end_header\n")
     assert b"element vertex 50" in head and len(body) == 50 * (24 + 3 + 1)
+
+
+def test_full_size_properties_headline_config():
+    """BASELINE's headline shape (4096 rays x 64 samples, fc_units 512) is too big for the CPU oracle, so the fused path
+    is held to properties that do not depend on size: run-to-run bit-reproducibility of results AND gradients
+    (slab reductions in fixed order, order-independent max for the operand scales), ray-permutation equivariance,
+    chunk invariance, and the physical invariants of the compositing (weights in [0,1], transparency non-increasing,
+    depth inside [near, far], labels = argmax of the logits)."""
+    from snerf_amd import ops
+    cfg = O.OracleCfg()                      # fc_units 512, 64 samples, 5 classes, siren
+    N, S = 4096, cfg.n_samples
+    pipe, _ = _pipeline_for(cfg, N, 11)
+    b = O.batch_to_torch(O.synthetic_batch(N, S, seed=12))
+    rays, extras, u = b["rays"].to(DEV), b["extras"].to(DEV), b["u"].to(DEV)
+    ro = {"perturb_rand": u}
+
+    def run(r, e, uu, grad):
+        for p in pipe.parameters():
+            p.grad = None
+        with torch.set_grad_enabled(grad):
+            res = pipe.renderer.render_rays(pipe.models, r, e, epoch=2, render_options={"perturb_rand": uu})
+            if grad:
+                (res["rgb_coarse"].square().mean() + res["sun_sc_coarse"].mean() + res["semantic_logits_coarse"].mean()
+                 + (res["beta_coarse"] * res["weights_coarse"].unsqueeze(-1)).mean()).backward()
+        return res
+
+    r1 = run(rays, extras, u, True)
+    g1 = {n: p.grad.clone() for n, p in pipe.named_parameters() if p.grad is not None}
+    r2 = run(rays, extras, u, True)
+    g2 = {n: p.grad.clone() for n, p in pipe.named_parameters() if p.grad is not None}
+    assert all(torch.equal(r1[k], r2[k]) for k in r1), "forward is not bit-reproducible"
+    assert g1.keys() == g2.keys() and all(torch.equal(g1[n], g2[n]) for n in g1), "gradients are not bit-reproducible"
+    assert all(torch.isfinite(g).all() for g in g1.values())
+    # permutation equivariance (exact: every ray's arithmetic is independent of its position in the batch, up to the
+    # per-tensor operand scales, which are permutation-invariant maxima)
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(DEV)
+    rp = run(rays[perm], extras[perm], u[perm], False)
+    rn = run(rays, extras, u, False)
+    for k in rn:
+        assert torch.equal(rp[k], rn[k][perm]), k
+    # physical invariants
+    w, T = rn["weights_coarse"], rn["transparency_coarse"]
+    assert float(w.min()) >= 0.0 and float(w.sum(1).max()) <= 1.0 + 1e-5
+    assert bool((T[:, 1:] <= T[:, :-1] + 1e-7).all()) and float(T.max()) <= 1.0 + 1e-6
+    # depth = sum(w * z) with z inside [near, far]: it cannot exceed the far bound (it is 0 for an empty ray)
+    assert bool((rn["depth_coarse"] <= rays[:, 7] + 1e-4).all()) and bool((rn["depth_coarse"] >= -1e-6).all())
+    assert torch.equal(rn["semantic_label_coarse"], rn["semantic_logits_coarse"].argmax(1))
+    assert float(rn["rgb_coarse"].min()) >= -1e-5 and torch.isfinite(rn["rgb_coarse"]).all()
+    # chunk invariance: halves rendered separately vs together differ only through the per-tensor operand scale
+    # (a power of two taken from each chunk's own maximum), i.e. by fp32 rounding
+    h = N // 2
+    ra, rb_ = run(rays[:h], extras[:h], u[:h], False), run(rays[h:], extras[h:], u[h:], False)
+    for k in ("rgb_coarse", "depth_coarse", "weights_coarse"):
+        both = torch.cat([ra[k], rb_[k]], 0)
+        assert float((both - rn[k]).abs().max()) <= 2e-5, k
