@@ -61,6 +61,11 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4& hi, bf16x4& mid, 
 // 22 significant bits of the scaled value; with hh + hl + lh the dropped lo*lo term is 2^-22 relative -- below the
 // rounding of an fp32 GEMM.  Returned as bf16x4 bit patterns (the LDS image is format-agnostic 16-bit data).
 __device__ __forceinline__ void split2h(const float4 v, float scale, bf16x4& hi, bf16x4& lo) {
+#ifdef SNERF_ABL_NOSPLIT  // diagnostic: (almost) no conversion work, planes not meaningful
+  { typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+    const u32x2n q = {__float_as_uint(v.x) ^ __float_as_uint(v.y), __float_as_uint(v.z) ^ __float_as_uint(v.w)};
+    hi = __builtin_bit_cast(bf16x4, q); lo = hi; (void)scale; return; }
+#endif
 #ifdef SNERF_ABL_CSPLIT   // plain C form (the compiler spends ~4.5 VALU per element on it)
   const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
   f16x4 h, l;
