@@ -679,6 +679,7 @@ int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, 
   g.planes = (narrow & 8) ? 1 : ((narrow & 16) ? 2 : 3);
   g.tile = (narrow & 32) ? 256 : ((narrow & 64) ? 128 : 0);
   if (narrow & 256) g.pp = 1;
+  if (narrow & 512) g.wide = 0;
   if (narrow & 128) {  // fp16 two-plane mode: operand maxima into scratch slots first
     static unsigned* slots = nullptr;
     if (!slots) SNERF_HIP_CHECK(hipMalloc(&slots, 2 * 64 * sizeof(unsigned)));

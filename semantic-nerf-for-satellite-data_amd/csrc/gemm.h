@@ -53,6 +53,7 @@ struct GemmArgs {
   int fmt = 0;
   const unsigned* a_max = nullptr; const unsigned* a2_max = nullptr; const unsigned* b_max = nullptr;
   unsigned* c_max = nullptr;
+  int wide = -1;          // K-contiguous, fmt 1, pre-split B: 1 = 128 x 256 tile, 0 = square tile, -1 = choose
   int pp = -1;            // 256 tile, fmt 1: 1 = ping-pong schedule, 0 = lockstep, -1 = default (lockstep; SNERF_X6_PP=1 overrides)
   int tile = 0;           // split kernel tile: 128, 256, or 0 = choose (256 when it wastes no more area than 128)
   int planes = 3;         // bf16 planes per operand of the split kernel: 3 fp32-class, 2 ~16-bit, 1 plain bf16

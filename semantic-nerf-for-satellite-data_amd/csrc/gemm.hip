@@ -23,6 +23,7 @@
 
 namespace snerf {
 
+void launch_wide(const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip: 128 x 256 tile, fp16 planes, pre-split B
 void launch_x6(bool ic, bool b_planes, int planes, int fmt, int tile, int pp, const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip
 
 template <int BI, bool IC>
@@ -271,6 +272,15 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
       p.tiles_i = (g.I + 255) / 256; p.tiles_j = (g.J + 255) / 256;
       grid.x = p.tiles_i * p.tiles_j;
     }
+    // K-contiguous launches of the default arithmetic with pre-split weights: 128 x 256 tile when the column padding
+    // is no worse than with 128-wide tiles (J = 256, 512, 1024 ...); SNERF_X6_WIDE=0 keeps the square tile (A/B)
+    static const bool wide_on = !(getenv("SNERF_X6_WIDE") && atoi(getenv("SNERF_X6_WIDE")) == 0);
+    const bool wide_fit = ((g.J + 255) / 256) * 256 == ((g.J + 127) / 128) * 128;
+    if (!A_IC && !B_IC && g.fmt == 1 && g.Bpl != nullptr && tile == 128 && g.k_split == 0 && (g.wide > 0 || (g.wide < 0 && wide_on && wide_fit))) {
+      p.tiles_j = (g.J + 255) / 256;
+      grid.x = p.tiles_i * p.tiles_j;
+      launch_wide(p, grid, stream);
+    } else
     launch_x6(A_IC, g.Bpl != nullptr && !A_IC, g.planes, g.fmt, tile, g.pp, p, grid, stream);
   }
   else hipLaunchKernelGGL((gemm_kernel<BI, BJ, WI, WJ, A_IC, B_IC>), grid, dim3(NT), 0, stream, p);

@@ -496,6 +496,132 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
 #endif
 }
 
+// ---- wide tile for the default arithmetic ---------------------------------------------------------------------------
+// 128 x 256 output tile, four waves of 64 x 128 (two workgroups per CU), K-contiguous A split on the fly into two fp16
+// planes, pre-split weight planes for B.  Per MFMA it stages half the A bytes (global loads, split, LDS writes) and reads
+// 25 % fewer fragment bytes than the 128 x 128 tile; the accumulators are kept as two 64-column halves so that each
+// half goes through the unchanged 64-wide epilogue.
+__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const KArgs p) {
+  constexpr int TI = 128, TJ = 256, MI = 2, NJ = 4, NP = 2;
+  constexpr int PA = TI * BK * 2, PB = TJ * BK * 2;          // bytes of one plane of the A / B tile
+  constexpr int OPA = NP * PA, OPB = NP * PB, STAGE = OPA + OPB;
+  constexpr int EPI_BYTES = epilogue_lds_floats(64, 4) * 4;
+  constexpr int LDS_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wi0 = (wave >> 1) * 64, wj0 = (wave & 1) * 128;
+  const float sa = scale_of_max(slots_max(p.amaxA, p.amaxA2, lane));
+  const float sb = scale_of_max(slots_max(p.amaxB, nullptr, lane));
+  __builtin_amdgcn_s_setprio(2);
+  int ti, tj;
+  tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);
+  const int i0 = ti * TI, j0 = tj * TJ;
+  const int kEnd = p.K;
+  const int nkt = (kEnd + BK - 1) / BK;
+
+  f32x16 acc[2][MI][2];   // [column half][block row][block column inside the half]
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][mi][nj][r] = 0.f;
+
+  const int Ka1 = min(p.Ka, p.K);
+  const srd_t srdA = srd_rows(p.A, p.lda, i0, p.I, Ka1);
+  const srd_t srdA2 = srd_rows(p.A2, p.lda2, i0, p.I, p.K - Ka1);
+  Loader<TI, false, 256> la1, la2;
+  la1.init(t, i0, p.I, p.lda);
+  la2.init(t, i0, p.I, p.lda2);
+  const srd_t srdBp = make_srd(p.Bpl, p.bytesBpl);
+  // the B tile of k-tile kt is PB contiguous bytes per plane; thread t moves the 16-byte chunks t and t + 256
+  const unsigned bp_base = ((unsigned)(p.bt_k0 >> 4) * (unsigned)p.bt_rows + (unsigned)(p.bt_row0 + j0)) * 32u + 16u * t;
+  const unsigned bp_step = (unsigned)p.bt_rows * 32u;
+  // rows of the weight matrix past its end (J not a multiple of 256) read whatever follows in the plane region or zeros:
+  // those columns are >= J and never stored
+  struct Tile { float4 ra[2]; u32x4 rbp[NP][2]; };
+  auto fetch = [&](int k0, Tile& r) {
+    const bool s2 = k0 >= p.Ka;
+    const srd_t sA = s2 ? srdA2 : srdA;
+    const unsigned kbA = s2 ? (unsigned)(k0 - p.Ka) * 4u : (unsigned)k0 * 4u;
+    const int kremA = s2 ? kEnd - k0 : min(kEnd, p.Ka) - k0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const unsigned base = s2 ? la2.base[q] : la1.base[q];
+      r.ra[q] = buf_load4(sA, (base != OOB && la1.kl[q] < kremA) ? base + kbA : OOB);
+    }
+    const unsigned o = (k0 < kEnd) ? bp_base + (unsigned)(k0 >> 4) * bp_step : OOB;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        r.rbp[pl][c] = __builtin_amdgcn_raw_buffer_load_b128(srdBp, o == OOB ? OOB : o + pl * p.pl_stride_bytes + c * 4096u, 0, 0);
+  };
+  auto store = [&](const Tile& r, char* stage) {
+    store_planes<false, NP, 128, 1>(r.ra, stage, t, sa);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) *reinterpret_cast<u32x4*>(stage + OPA + pl * PB + 16 * t + c * 4096) = r.rbp[pl][c];
+  };
+  auto ktile = [&](int kt, Tile& r) {
+    const char* sA = lds + (kt & 1) * STAGE;
+    const char* sB = sA + OPA;
+    char* dst = lds + ((kt + 1) & 1) * STAGE;
+    bf16x8 b[NP][NJ], a[2][NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+      for (int nj = 0; nj < NJ; ++nj) b[pl][nj] = load_frag<false, 128>(sB + pl * PB, wj0 + 32 * nj, lane);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) a[mi][pl] = load_frag<false, 128>(sA + pl * PA, wi0 + 32 * mi, lane);
+    auto block = [&](int mi, int nj) {
+      f32x16 c = acc[nj >> 1][mi][nj & 1];
+      const f16x8 ah = __builtin_bit_cast(f16x8, a[mi][0]), al = __builtin_bit_cast(f16x8, a[mi][1]);
+      const f16x8 bh = __builtin_bit_cast(f16x8, b[0][nj]), bl = __builtin_bit_cast(f16x8, b[1][nj]);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+      acc[nj >> 1][mi][nj & 1] = c;
+    };
+    block(0, 0); block(0, 1); block(0, 2); block(0, 3);
+    store(r, dst);
+    block(1, 0); block(1, 1); block(1, 2); block(1, 3);
+    fetch((kt + 3) * BK, r);
+    __syncthreads();
+  };
+
+  Tile r0, r1;
+  fetch(0, r0);
+  store(r0, lds);
+  fetch(BK, r0);
+  fetch(2 * BK, r1);
+  __syncthreads();
+  __builtin_amdgcn_s_setprio(0);
+  for (int kt = 0; kt < nkt; kt += 2) {
+    ktile(kt, r0);
+    ktile(kt + 1, r1);
+  }
+  __builtin_amdgcn_s_setprio(2);
+  if (i0 + wi0 >= p.I) return;
+  const float inv = 1.f / (sa * sb);
+  // two explicit calls (a loop over the halves would make `acc` a dynamically indexed array, i.e. scratch memory)
+  if (j0 + wj0 < p.J)        // wave-uniform
+    gemm_epilogue_dispatch<MI, 2, 64>(acc[0], reinterpret_cast<float*>(lds), wave, lane, i0 + wi0, j0 + wj0, p, p.C, inv);
+  if (j0 + wj0 + 64 < p.J)
+    gemm_epilogue_dispatch<MI, 2, 64>(acc[1], reinterpret_cast<float*>(lds), wave, lane, i0 + wi0, j0 + wj0 + 64, p, p.C, inv);
+}
+
+void launch_wide(const KArgs& p, dim3 grid, hipStream_t stream) {
+  hipLaunchKernelGGL(gemm_wide_kernel, grid, dim3(256), 0, stream, p);
+}
+
 template <int NP, int BT, int FMT = 0, bool PP = false>
 static void launch_np(bool ic, bool b_planes, const KArgs& p, dim3 grid, hipStream_t stream) {
   const dim3 block(TileCfg<BT>::NTH);
