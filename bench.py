@@ -216,7 +216,7 @@ def main():
     step_tflops = flops_step_gpu * args.steps / dt / 1e12  # per GPU, algorithmic (SURVEY 8d figure)
     if prof is not None:
         x6 = mode != "fp32"
-        # dominant kernel = variant 0: gemm_x6_kernel<false,true,3,128> (forward X.W^T and dX), ~64 % of device time
+        # dominant kernel = variant 0: the K-contiguous launches (forward X.W^T and dX; gemm_wide_kernel), ~61 % of device time
         ms, fl, n = prof.ms[0], prof.flops[0], prof.launches[0]
         fp32_eq = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         fam_ms = sum(prof.ms[v] for v in range(3)); fam_fl = sum(prof.flops[v] for v in range(3))
@@ -227,11 +227,12 @@ def main():
         achieved = fp32_eq * mult
         # HBM bytes per launch of that kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
         # the MI355X guide), measured on this exact workload: profiles/r01/pmc_hbm_traffic.md
-        traffic = 1.359e9 if (mode == "f16x2" and args.rays == 4096 and args.samples == 64) else None
+        traffic = 1.298e9 if (mode == "f16x2" and args.rays == 4096 and args.samples == 64) else None
         line["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "kernel": (("snerf::gemm_x6_kernel<false,true,2,128,1,false> (two fp16 planes of power-of-two-scaled fp32 operands, hh + hl + lh = 3 x "
-                        "v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulate; forward X.W^T and dX launches)" if mode == "f16x2" else
+            "kernel": (("snerf::gemm_wide_kernel (128x256 tile; two fp16 planes of power-of-two-scaled fp32 operands, hh + hl + lh = 3 x "
+                        "v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulate; forward X.W^T and dX launches; the two launches per "
+                        "step whose width does not fit run the 128x128 tile of gemm_x6_kernel and are averaged in)" if mode == "f16x2" else
                         "snerf::gemm_x6_kernel<false,true,NP,128> (split-bf16: NP bf16 planes per fp32 operand, 6 / 3 / 1 x v_mfma_f32_32x32x16_bf16 per "
                         "32x32x16 block for NP = 3 / 2 / 1, fp32 accumulate; forward X.W^T and dX launches)") if x6 else
                        "snerf::gemm_kernel<128,128,64,64,false,false> (v_mfma_f32_32x32x2_f32)"),
