@@ -199,11 +199,14 @@ def main():
         "metric": "train rays/sec (4096 rays x 64 samples)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None,
-        "dtype": {"split3": "f32 (fp32 storage and accumulate; products on bf16 MFMA via 3-plane splits, fp32-level accuracy)",
-                  "f16x2": "f32 (fp32 storage and accumulate; products on fp16 MFMA via 2-plane splits of power-of-two-scaled operands, fp32-level accuracy)",
-                  "fp32": "f32", "split2": "REDUCED: f32 storage/accumulate, operands as 2 bf16 planes (~16 bits, torch 'high')",
-                  "bf16": "REDUCED: bf16 operands, f32 accumulate and storage (torch 'medium' / precision=16)",
-                  "split3_bwd2": "f32 forward (3-plane splits, fp32-level results); REDUCED backward: 2 bf16 planes (~16 bits) in dX / dW"}[mode],
+        # storage and accumulation are fp32 in every mode; `arithmetic` says how the products are formed
+        "dtype": {"f16x2": "f32", "split3": "f32", "fp32": "f32", "split3_bwd2": "f32 forward / REDUCED backward",
+                  "split2": "REDUCED (fp32 as two bf16, ~16 bits)", "bf16": "bf16 (REDUCED)"}[mode],
+        "arithmetic": {"split3": "fp32 storage and accumulate; products on bf16 MFMA via 3-plane splits, fp32-level accuracy",
+                       "f16x2": "fp32 storage and accumulate; products on fp16 MFMA via 2-plane splits of power-of-two-scaled operands, fp32-level accuracy",
+                       "fp32": "v_mfma_f32_32x32x2_f32", "split2": "REDUCED: f32 storage/accumulate, operands as 2 bf16 planes (~16 bits, torch 'high')",
+                       "bf16": "REDUCED: bf16 operands, f32 accumulate and storage (torch 'medium' / precision=16)",
+                       "split3_bwd2": "f32 forward (3-plane splits, fp32-level results); REDUCED backward: 2 bf16 planes (~16 bits) in dX / dW"}[mode],
         "data": "synthetic",
         "config": {"workload": "JAX_068 semantic pipeline (configs[1]): RSSemanticNeRF fc_units=512 x 8 layers, C=5, "
                                f"{args.rays} rays x {args.samples} samples per GPU, fp32, main + solar-correction pass, "
