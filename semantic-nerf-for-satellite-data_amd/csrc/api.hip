@@ -405,9 +405,10 @@ static int dw_reduce(const Plan& p, WS ws, const DwMat& m, size_t count, float* 
 static int bias_from_colsum(const Plan& p, WS ws, int width, float* gout, hipStream_t st) {
   return reduce_partials(ws.f(p.o_colsum), p.nrb, (size_t)p.maxw, width, ws.f(p.o_colsum2), gout, st);
 }
-static int bias_from_narrow(const Plan& p, WS ws, const float* dnar, float* gout, hipStream_t st) {
-  const int nb = (p.P + 1023) / 1024;
-  RC(launch_colsum32(dnar, p.P, ws.f(p.o_colsum), st));
+// bias gradient of a NARROW-wide pre-activation buffer; the same pass leaves the buffer's |max| in `slots` (fp16-plane mode)
+static int bias_from_narrow(const Plan& p, WS ws, const float* dnar, float* gout, hipStream_t st, unsigned* slots = nullptr) {
+  const int nb = colsum32_blocks(p.P);
+  RC(launch_colsum32(dnar, p.P, ws.f(p.o_colsum), st, slots));
   return reduce_partials(ws.f(p.o_colsum), nb, NARROW, NARROW, ws.f(p.o_colsum2), gout, st);
 }
 
@@ -438,9 +439,8 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
   RC(launch_composite_bwd(b, st));
   if (p.fmt == 1) {
     SNERF_HIP_CHECK(hipMemsetAsync(slot(p, ws, p.n_fwd_slots), 0, (size_t)(p.n_slots - p.n_fwd_slots) * 64 * sizeof(unsigned), st));
-    RC(launch_absmax(dsig, P, NARROW, NARROW, slot(p, ws, p.s_dsig), st));
-    RC(launch_absmax(dsun, P, NARROW, NARROW, slot(p, ws, p.s_dsun), st));
-    if (!p.sc) RC(launch_absmax(dfin, P, NARROW, NARROW, slot(p, ws, p.s_dfin), st));
+    // the |max| of dsig / dsun / dfin comes out of their bias-gradient pass (bias_from_narrow), each before its first
+    // scaled consumer
   }
   if (!p.sc)
     RC(reduce_partials(ws.f(p.o_skyslab), p.comp_blocks * 4, (size_t)p.sky_floats, p.sky_floats, ws.f(p.o_colsum2),
@@ -453,7 +453,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     const DwMat mf = dw_begin(p, NARROW, p.KF, p.KF, true);
     RC(dw_gemm(p, ws, mf, dfin, NARROW, NARROW, true, ws.f(p.o_h1), p.h1w, p.KF, 0, st));
     RC(dw_reduce(p, ws, mf, (size_t)NARROW * p.KF, gp + p.w_fin, st));
-    RC(bias_from_narrow(p, ws, dfin, gp + p.b_fin, st));
+    RC(bias_from_narrow(p, ws, dfin, gp + p.b_fin, st, slot(p, ws, p.s_dfin)));
     GemmArgs g;  // dz1[:, :KF] = (dfin . W_fin) * act'
     g.A = dfin; g.lda = NARROW; weights(g, p, pk, p.t_fin, p.KF, NARROW); g.I = P; g.J = p.KF; g.K = NARROW;
     g.C = dz1; g.ldc = p.h1w; dact(g, p.o_c1, p.o_h1, p.h1w);
@@ -467,7 +467,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     const DwMat mh = dw_begin(p, H, H, H, false);
     RC(dw_gemm(p, ws, m4, dsun, NARROW, NARROW, true, ws.f(p.o_s3), H, H, 0, st));
     RC(dw_reduce(p, ws, m4, (size_t)NARROW * H, gp + p.w_s4, st));
-    RC(bias_from_narrow(p, ws, dsun, gp + p.b_s4, st));
+    RC(bias_from_narrow(p, ws, dsun, gp + p.b_s4, st, slot(p, ws, p.s_dsun)));
     GemmArgs g;
     g.A = dsun; g.lda = NARROW; weights(g, p, pk, p.t_s4, H, NARROW); g.I = P; g.J = H; g.K = NARROW;
     g.C = ws.f(p.o_dsa); g.ldc = H; dact(g, p.o_cs3, p.o_s3, H);
@@ -513,7 +513,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     RC(dw_gemm(p, ws, ms, dfa, p.FA, W, false, hl, W, W, 0, st, p.s_dfa, p.s_h[p.L - 1]));
     RC(dw_gemm(p, ws, ms, dsig, NARROW, NARROW, true, hl, W, W, (size_t)W * W, st));
     RC(dw_reduce(p, ws, ms, (size_t)(W + NARROW) * W, gp + p.w_fs, st));
-    RC(bias_from_narrow(p, ws, dsig, gp + p.b_fs + W, st));
+    RC(bias_from_narrow(p, ws, dsig, gp + p.b_fs + W, st, slot(p, ws, p.s_dsig)));
     GemmArgs g;
     g.A = dfa; g.lda = p.FA; g.Ka = W; g.A2 = dsig; g.lda2 = NARROW;
     weights(g, p, pk, p.t_fs, W, W + NARROW); g.I = P; g.J = W; g.K = W + NARROW;

@@ -32,7 +32,8 @@ int launch_absmax(const float* x, int rows, int cols, int ld, unsigned* slots, h
 int launch_reduce_rows(const float* in, int n_in, size_t in_stride, int width, float* out, size_t out_stride,
                        int group, int accumulate, hipStream_t st);
 int reduce_partials(const float* in, int n_in, size_t in_stride, int width, float* tmp, float* out, hipStream_t st);
-int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st);
+int colsum32_blocks(int rows);   // partial rows launch_colsum32 writes
+int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st, unsigned* slots = nullptr);
 int launch_ray_sum(const float* dfa, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st);
 
 }  // namespace snerf

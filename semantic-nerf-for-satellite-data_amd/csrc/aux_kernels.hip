@@ -288,28 +288,49 @@ int reduce_partials(const float* in, int n_in, size_t in_stride, int width, floa
   return launch_reduce_rows(tmp, ng, (size_t)width, width, out, 0, ng, 1, st);
 }
 
-// column sums of a [rows][32] buffer -> partial[blocks][32] (1024 rows per block)
-__global__ void colsum32_kernel(const float* __restrict__ in, int rows, float* __restrict__ partial) {
-  __shared__ float sm[8][32];
-  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
-  const int r0 = blockIdx.x * 1024;
-  float s = 0.f;
-  for (int i = 0; i < 128; ++i) {
-    const int r = r0 + rg + 8 * i;
-    if (r < rows) s += in[(size_t)r * 32 + col];
-  }
-  sm[rg][col] = s;
-  __syncthreads();
-  if (rg == 0) {
-    float t = 0.f;
+// column sums of a [rows][32] buffer -> partial[blocks][32] (256 rows per block, float4 loads: 8 lanes per row), and
+// optionally the buffer's |max| into 64 slots (the same pass serves the bias gradient and the operand scale)
+constexpr int CS32_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum32_kernel(const float* __restrict__ in, int rows, float* __restrict__ partial,
+                                                       unsigned* __restrict__ slots) {
+  __shared__ float4 sm[32][8];
+  __shared__ float smax[4];
+  const int c4 = threadIdx.x & 7, rg = threadIdx.x >> 3;   // 32 row groups x 8 column quads
+  const int r0 = blockIdx.x * CS32_ROWS;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  float m = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += sm[i][col];
-    partial[blockIdx.x * 32 + col] = t;
+  for (int i = 0; i < CS32_ROWS / 32; ++i) {
+    const int r = r0 + rg + 32 * i;
+    if (r < rows) {
+      const float4 v = *reinterpret_cast<const float4*>(in + (size_t)r * 32 + 4 * c4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+  }
+  sm[rg][c4] = s;
+  if (slots != nullptr) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {   // fixed summation order over the 32 row groups
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const float4 v = sm[i][threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * 32 + 4 * threadIdx.x) = t;
+  }
+  if (slots != nullptr && threadIdx.x == 0) {
+    m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    if (m > 0.f) atomicMax(slots + (blockIdx.x & 63), __float_as_uint(m));
   }
 }
 
-int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st) {
-  hipLaunchKernelGGL(colsum32_kernel, dim3((rows + 1023) / 1024), dim3(256), 0, st, in, rows, partial);
+int colsum32_blocks(int rows) { return (rows + CS32_ROWS - 1) / CS32_ROWS; }
+
+int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st, unsigned* slots) {
+  hipLaunchKernelGGL(colsum32_kernel, dim3(colsum32_blocks(rows)), dim3(256), 0, st, in, rows, partial, slots);
   SNERF_LAUNCH_CHECK();
   return 0;
 }
