@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNERF_ABI_VERSION 1
+#define SNERF_ABI_VERSION 2
 #define SNERF_MAX_LAYERS 16
 
 /* error codes */
@@ -45,23 +45,23 @@ extern "C" {
                                  trunk + sigma + sun-visibility branch and return weights/transparency/sun
                                  (semantic/components/rendering.py:59-78) */
 
-#define SNERF_FLAG_FP32_MFMA 4u /* contract on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32) instead of the default
-                                  split-bf16 form (three bf16 planes per fp32 operand, six v_mfma_f32_32x32x16_bf16
-                                  products, fp32 accumulate: same accuracy class, 2.7x less matrix-pipe time) */
-
+/* Arithmetic of the dense contractions.  With NONE of the arithmetic bits set a pass runs the default, SNERF_FLAG_F16X2
+ * (the same for C and Python callers); the other bits select the alternatives and exclude each other. */
+#define SNERF_FLAG_F16X2 64u   /* DEFAULT (flags = 0 means this): fp32-class arithmetic on the fp16 matrix cores.  Every operand
+                                  is scaled by a power of two, split into two fp16 planes (22 significant bits) and contracted
+                                  as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation; the dropped
+                                  lo*lo term is 2^-22 relative, below an fp32 GEMM's own rounding (normwise) */
+#define SNERF_FLAG_SPLIT3 128u /* fp32-class, conservative: three bf16 planes per fp32 operand (24 significant bits whatever the
+                                  magnitude), six v_mfma_f32_32x32x16_bf16 products, fp32 accumulate; twice the matrix work of
+                                  the default */
+#define SNERF_FLAG_FP32_MFMA 4u /* contract on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32): exact fp32 products at 1/16
+                                  of the 16-bit matrix rate (diagnostics) */
 #define SNERF_FLAG_BF16 8u     /* REDUCED precision (the reference's `precision = 16` runs; BASELINE.json configs[2], [4]):
                                   operands rounded to one bf16 plane, one MFMA product, fp32 accumulate, fp32 storage.
                                   Judged on PSNR / mIoU, not on the 1e-4 parity bar. */
 #define SNERF_FLAG_BF16X3 16u  /* REDUCED precision: two bf16 planes (hi | mid), products hh + hm + mh: ~16 significant bits */
-
-#define SNERF_FLAG_BWD_BF16X3 32u /* REDUCED precision in snerf_backward only: forward results keep the default fp32-class
-                                   arithmetic (the 1e-4 output bar), the dX / dW contractions use two planes (gradients
-                                   ~1e-4 relative) */
-
-#define SNERF_FLAG_F16X2 64u   /* fp32-class arithmetic on HALF the matrix work: every operand is scaled by a power of two taken
-                                  from its |max| (tracked on the device), split into two fp16 planes (22 significant bits) and
-                                  contracted as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation; the
-                                  dropped lo*lo term is 2^-22 relative, below an fp32 GEMM's own rounding (normwise) */
+#define SNERF_FLAG_BWD_BF16X3 32u /* SNERF_FLAG_SPLIT3 forward (the 1e-4 output bar) and REDUCED precision in snerf_backward only:
+                                   the dX / dW contractions use two bf16 planes (gradients ~1e-4 relative) */
 
 /* Model + batch description.  Field names follow the reference config
  * (configs/pipelines/rs_semantic.toml:13-67, semantic/pipelines/rs_semantic.py:125-141). */
@@ -237,7 +237,9 @@ typedef struct SnerfLossGrads { /* any may be NULL */
 size_t snerf_loss_workspace_bytes(const SnerfLossCfg* cfg);
 int snerf_loss_partial(const SnerfLossCfg* cfg, const SnerfLossIn* in, float* totals, void* workspace,
                        size_t workspace_bytes, void* stream);
-/* n_rays_global = number of rays the means run over (sum over ranks); grads are scaled by grad_scale */
+/* n_rays_global = number of rays the means run over (sum over ranks), or 0 = use the ray count that snerf_loss_partial
+ * summed into `totals` (all-reduced with the other sums, so unequal shards are handled); grads are scaled by grad_scale.
+ * A label outside [0, n_classes) that is not ignore_index makes the CE term NaN (torch raises there). */
 int snerf_loss_finish(const SnerfLossCfg* cfg, const SnerfLossIn* in, const float* totals, float n_rays_global,
                       float grad_scale, float* terms, const SnerfLossGrads* grads, void* stream);
 

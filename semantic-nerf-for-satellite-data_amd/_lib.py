@@ -5,16 +5,20 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsnerf_hip.so")
 MAX_LAYERS = 16
+ABI_VERSION = 2   # include/snerf_hip.h SNERF_ABI_VERSION
 
 FLAG_TRAIN = 1
 FLAG_SC_PASS = 2
-FLAG_FP32_MFMA = 4  # contract on v_mfma_f32_32x32x2_f32 instead of the default split-bf16 (x6) form
-FLAG_BF16 = 8       # reduced precision: one bf16 plane per operand (precision = 16 / float32_matmul_precision "medium")
-FLAG_BF16X3 = 16    # reduced precision: two bf16 planes, three products (float32_matmul_precision "high")
+# arithmetic bits of SnerfDesc.flags (include/snerf_hip.h): none set = the default, f16x2
+FLAG_F16X2 = 64       # default: fp32-class on the fp16 matrix cores, two fp16 planes of power-of-two-scaled operands
+FLAG_SPLIT3 = 128     # fp32-class, three bf16 planes / six products
+FLAG_FP32_MFMA = 4    # v_mfma_f32_32x32x2_f32 (diagnostics)
+FLAG_BF16 = 8         # reduced precision: one bf16 plane per operand (precision = 16 / float32_matmul_precision "medium")
+FLAG_BF16X3 = 16      # reduced precision: two bf16 planes, three products (float32_matmul_precision "high")
+FLAG_BWD_BF16X3 = 32  # split3 forward, reduced precision (two planes) in the backward contractions only
 # ModelSpec.mfma -> SnerfDesc.flags
-FLAG_BWD_BF16X3 = 32  # reduced precision (two planes) in the backward contractions only
-FLAG_F16X2 = 64       # fp32-class on half the matrix work: two fp16 planes of power-of-two-scaled operands
-MFMA_FLAGS = {"f16x2": FLAG_F16X2, "split3": 0, "fp32": FLAG_FP32_MFMA, "split2": FLAG_BF16X3, "bf16": FLAG_BF16, "split3_bwd2": FLAG_BWD_BF16X3}
+MFMA_FLAGS = {"f16x2": 0, "split3": FLAG_SPLIT3, "fp32": FLAG_FP32_MFMA, "split2": FLAG_BF16X3, "bf16": FLAG_BF16,
+              "split3_bwd2": FLAG_BWD_BF16X3}
 
 _fp = C.POINTER(C.c_float)
 
@@ -142,8 +146,8 @@ def lib():
     L.snerf_profile_begin.restype = C.c_int
     L.snerf_profile_end.restype = C.c_int
     L.snerf_profile_end.argtypes = [C.POINTER(SnerfProfile)]
-    if L.snerf_version() != 1:
-        raise RuntimeError(f"libsnerf_hip.so ABI version {L.snerf_version()} != 1")
+    if L.snerf_version() != ABI_VERSION:
+        raise RuntimeError(f"libsnerf_hip.so ABI version {L.snerf_version()} != {ABI_VERSION}")
     _lib = L
     return L
 

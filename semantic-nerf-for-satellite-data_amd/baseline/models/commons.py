@@ -3,22 +3,28 @@
 The activation and the positional mapping are computed inside the fused HIP kernels (GEMM epilogue /
 encode kernel); the classes here only carry the hyper-parameters and the initialisers so that
 nn.Module trees, state_dict keys and init distributions equal the reference's."""
-import numpy as np
+import math
+
 import torch
 
 
+def _uniform_by_fan_in(module, bound_of_fan_in):
+    """U(-b, b) on `module.weight` with b a function of the layer's fan-in; biases (and modules without a weight, as
+    `Sequential.apply` also visits the activations) keep what they have -- PyTorch's default Linear init."""
+    w = getattr(module, "weight", None)
+    if w is not None:
+        b = float(bound_of_fan_in(w.shape[-1]))
+        torch.nn.init.uniform_(w, -b, b)
+
+
 def sine_init(m):
-    with torch.no_grad():
-        if hasattr(m, "weight"):
-            n = m.weight.size(-1)
-            m.weight.uniform_(-np.sqrt(6 / n), np.sqrt(6 / n))
+    """SIREN hidden layers: b = sqrt(6 / fan_in) (baseline/models/commons.py:5-10)"""
+    _uniform_by_fan_in(m, lambda n: math.sqrt(6.0 / n))
 
 
 def first_layer_sine_init(m):
-    with torch.no_grad():
-        if hasattr(m, "weight"):
-            n = m.weight.size(-1)
-            m.weight.uniform_(-1 / n, 1 / n)
+    """SIREN first layer: b = 1 / fan_in (baseline/models/commons.py:13-18)"""
+    _uniform_by_fan_in(m, lambda n: 1.0 / n)
 
 
 class _FusedOnly(torch.nn.Module):

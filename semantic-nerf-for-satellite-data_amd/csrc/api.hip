@@ -58,13 +58,15 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.tau = d->t_dim; p.C = d->n_classes;
   p.siren = d->siren != 0; p.sem_sigmoid = d->sem_sigmoid != 0;
   p.train = (d->flags & SNERF_FLAG_TRAIN) != 0; p.sc = (d->flags & SNERF_FLAG_SC_PASS) != 0;
-  p.x6 = (d->flags & SNERF_FLAG_FP32_MFMA) == 0;
-  p.planes = (d->flags & SNERF_FLAG_BF16) ? 1 : ((d->flags & SNERF_FLAG_BF16X3) ? 2 : 3);
-  if (d->flags & SNERF_FLAG_F16X2) {
-    if (d->flags & (SNERF_FLAG_FP32_MFMA | SNERF_FLAG_BF16 | SNERF_FLAG_BF16X3 | SNERF_FLAG_BWD_BF16X3)) return bad("SNERF_FLAG_F16X2 excludes the other arithmetic flags");
-    p.fmt = 1; p.planes = 2;
+  {  // arithmetic: at most one of the selecting bits; none = the default (SNERF_FLAG_F16X2), for C and Python callers alike
+    const unsigned sel = d->flags & (SNERF_FLAG_F16X2 | SNERF_FLAG_SPLIT3 | SNERF_FLAG_FP32_MFMA | SNERF_FLAG_BF16 |
+                                     SNERF_FLAG_BF16X3 | SNERF_FLAG_BWD_BF16X3);
+    const bool bwd2_on_split3 = sel == (SNERF_FLAG_SPLIT3 | SNERF_FLAG_BWD_BF16X3);   // the second implies the first
+    if ((sel & (sel - 1)) != 0 && !bwd2_on_split3) return bad("more than one arithmetic flag (SNERF_FLAG_F16X2 / SPLIT3 / FP32_MFMA / BF16 / BF16X3 / BWD_BF16X3)");
+    p.x6 = (sel & SNERF_FLAG_FP32_MFMA) == 0;
+    p.planes = (sel & SNERF_FLAG_BF16) ? 1 : ((sel & SNERF_FLAG_BF16X3) ? 2 : 3);
+    if (sel == 0 || sel == SNERF_FLAG_F16X2) { p.fmt = 1; p.planes = 2; }
   }
-  if (!p.x6 && p.planes != 3) return bad("SNERF_FLAG_FP32_MFMA excludes the bf16 flags");
   p.skip_mask = d->skip_mask;
   const bool sem = p.C > 0;
   const bool sbeta = sem && d->use_separate_beta_for_s;
@@ -658,7 +660,7 @@ int snerf_backward(const SnerfDesc* desc, const float* packed_params, const Sner
   if (((uintptr_t)workspace & 255) || ((uintptr_t)packed_params & 255) || ((uintptr_t)packed_grads & 255)) { set_error("workspace and packed buffers must be 256-byte aligned"); return SNERF_ERR_WORKSPACE; }
   RC(check_inputs(p, in));
   WS ws{(char*)workspace};
-  if ((desc->flags & SNERF_FLAG_BWD_BF16X3) && p.x6 && p.planes == 3) p.planes = 2;  // same Plan, fewer products in backward
+  if ((desc->flags & SNERF_FLAG_BWD_BF16X3) && p.x6 && p.fmt == 0 && p.planes == 3) p.planes = 2;  // same Plan, fewer products in backward
   return backward_impl(p, packed_params, in, gout, packed_grads, d_t, d_t_s, ws, (hipStream_t)stream);
 }
 

@@ -1,13 +1,13 @@
-// Split-bf16 GEMM for gfx950: fp32 operands, fp32 result, fp32-level accuracy, contraction on the bf16
-// matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate).
+// Split-plane GEMMs for gfx950: fp32 operands, fp32 result, fp32-class accuracy, contraction on the 16-bit matrix cores
+// (v_mfma_f32_32x32x16_{f16,bf16}, 16x the fp32 MFMA rate).  One kernel template, two operand formats:
 //
-// Every fp32 operand element a is split ON THE FLY (in the tile loader, between the global load and the
-// LDS store) into three bf16 planes a = hi + mid + lo (each the bf16 rounding of the running residual;
-// residuals are exact in fp32, so the planes carry 24 significant bits).  A product a*b is then the sum of
-// the six plane products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- each exact in the fp32
-// accumulator (8 x 8 bit) -- and the dropped terms are <= 2^-26 |a b|, below fp32's own rounding.  Six bf16
-// MFMAs (6 x 32 cycles) replace eight fp32 MFMAs (8 x 64 cycles) per 32x32x16 block: 2.67x less matrix-
-// pipe time at unchanged numerics, with HBM traffic and the fused epilogue (gemm_common.h) unchanged.
+//   FMT 1, NP 2 (SNERF_FLAG_F16X2, the DEFAULT arithmetic): every operand element, times its tensor's power-of-two
+//     scale, is split ON THE FLY (in the tile loader, between the global load and the LDS store) into two fp16 planes
+//     hi + lo; a product is hi*hi + hi*lo + lo*hi (three MFMAs), the dropped lo*lo term is 2^-22 relative.
+//   FMT 0, NP 3 (SNERF_FLAG_SPLIT3): three bf16 planes a = hi + mid + lo (each the bf16 rounding of the running
+//     residual; residuals are exact in fp32, so the planes carry 24 significant bits); a product is the six plane
+//     products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- each exact in the fp32 accumulator -- and the dropped
+//     terms are <= 2^-26 |a b|, below fp32's own rounding.  NP 2 / NP 1 of this format are the REDUCED modes.
 //
 // LDS images (BK = 16, per plane):
 //   KC source (k contiguous: activations X[M][K], weights W[N][K]): [row][16 k] bf16 = 32-B rows; the MFMA

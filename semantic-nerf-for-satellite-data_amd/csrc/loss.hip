@@ -54,7 +54,9 @@ __device__ __forceinline__ RayLoss ray_loss(const SnerfLossCfg& c, const SnerfLo
       for (int k = 0; k < c.n_classes; ++k) se += expf(l[k] - mx);
       r.mx = mx;
       r.lse = logf(se);
-      if (r.valid_ce) r.ce = (mx + r.lse) - l[y];  // -log_softmax(l)[y]
+      // a label outside [0, C) that is not the ignore index makes torch's cross_entropy raise (semantic/components/loss.py:52-54);
+      // an asynchronous kernel cannot raise, so the term (and with it the total loss) becomes NaN -- never an out-of-range read
+      if (r.valid_ce) r.ce = (y >= 0 && y < (long long)c.n_classes) ? (mx + r.lse) - l[y] : __builtin_nanf("");  // -log_softmax(l)[y]
     }
   }
   return r;
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(SnerfLossCfg c, Snerf
 }
 
 __global__ __launch_bounds__(256) void loss_finish_kernel(SnerfLossCfg c, SnerfLossIn in, const float* __restrict__ tot,
-                                                          float Ng, float gs, float* __restrict__ terms, SnerfLossGrads g) {
+                                                          float Ng_arg, float gs, float* __restrict__ terms, SnerfLossGrads g) {
+  const float Ng = Ng_arg > 0.f ? Ng_arg : tot[T_N];   // 0: the ray count summed (and all-reduced) with the other totals
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nwaves = gridDim.x * 4;
@@ -237,7 +240,7 @@ int snerf_loss_finish(const SnerfLossCfg* cfg, const SnerfLossIn* in, const floa
   int rc = check_loss(cfg, in);
   if (rc) return rc;
   if (!totals || !grads) { set_error("snerf_loss_finish: null argument"); return SNERF_ERR_NULL; }
-  if (!(n_rays_global > 0.f)) { set_error("snerf_loss_finish: n_rays_global must be positive"); return SNERF_ERR_BAD_DESC; }
+  if (!(n_rays_global >= 0.f)) { set_error("snerf_loss_finish: n_rays_global must be positive, or 0 to take the count from totals"); return SNERF_ERR_BAD_DESC; }
   hipLaunchKernelGGL(loss_finish_kernel, dim3(loss_blocks(cfg->n_rays)), dim3(256), 0, (hipStream_t)stream, *cfg, *in,
                      totals, n_rays_global, grad_scale, terms, *grads);
   SNERF_LAUNCH_CHECK();

@@ -4,6 +4,19 @@ from collections import defaultdict
 import torch
 
 
+_PER_RAY_OPTIONS = ("perturb_rand", "given_z_vals")   # (N, S) tensors a caller may pin for the whole frame
+
+
+def _chunk_options(render_options, i, chunk, n):
+    """render options of the chunk starting at ray i: per-ray tensors given for the whole frame are sliced"""
+    opts = dict(render_options) if render_options else {}
+    for k in _PER_RAY_OPTIONS:
+        v = opts.get(k)
+        if torch.is_tensor(v) and v.shape[0] == n and n > chunk:
+            opts[k] = v[i:i + chunk]
+    return opts
+
+
 @torch.no_grad()
 def batched_inference(cfgs, renderer, models, rays, extras, render_options={}, epoch=None, show_tqdm=False):
     chunk = cfgs.pipeline.render_chunk_size
@@ -14,7 +27,7 @@ def batched_inference(cfgs, renderer, models, rays, extras, render_options={}, e
         steps = tqdm(steps)
     for i in steps:
         r = renderer.render_rays(models, rays[i:i + chunk], extras[i:i + chunk] if extras is not None else None,
-                                 epoch=epoch, render_options=render_options)
+                                 epoch=epoch, render_options=_chunk_options(render_options, i, chunk, rays.shape[0]))
         for k, v in r.items():
             parts[k].append(v)
     return {k: (v[0] if len(v) == 1 else torch.cat(v, 0)) for k, v in parts.items()}
@@ -50,14 +63,16 @@ def lean_inference(cfgs, renderer, models, rays, extras, keys=("rgb_coarse", "de
             raise KeyError(f"lean_inference: unknown result '{k}'")
         dt = torch.int64 if bare == "semantic_label" else torch.float32
         out[bare + "_coarse"] = torch.empty((n,) + _KEY_SHAPES[bare](S, Cn), dtype=dt, device=rays.device)
-    opts = dict(render_options) if render_options else {}
-    opts["packed_params"] = ops.pack_params(model.spec, dict(model.named_parameters()))
+    packed = ops.pack_params(model.spec, dict(model.named_parameters()))
+    ws = None
     steps = range(0, n, chunk)
     if show_tqdm:
         from tqdm import tqdm
         steps = tqdm(steps)
     for i in steps:
         sl = {k: v[i:i + chunk] for k, v in out.items()}
-        opts["workspace"] = renderer.render_rays_into(models, rays[i:i + chunk],
-                                                       extras[i:i + chunk] if extras is not None else None, sl, opts)
+        opts = _chunk_options(render_options, i, chunk, n)
+        opts["packed_params"], opts["workspace"] = packed, ws
+        ws = renderer.render_rays_into(models, rays[i:i + chunk], extras[i:i + chunk] if extras is not None else None,
+                                       sl, opts)
     return out

@@ -67,6 +67,18 @@ class GpuRayBank:
             t["semantic_sparsity_mask"] = torch.ones(n_rays, dtype=torch.bool)
         return GpuRayBank(t, n_classes=n_classes, car_cls_idx=n_classes - 1, seed=seed, device=device)
 
+    def n_images(self, rays_per_image: int) -> int:
+        return len(self) // rays_per_image
+
+    def image(self, i: int, rays_per_image: int, rank: int = 0, world: int = 1) -> dict:
+        """rows of validation "image" i (the reference's test DataLoader hands over one image's H*W rays per step,
+        framework/pipelines.py:120-129); under data parallelism each rank takes a contiguous slice of the image's rays
+        (ragged tails allowed: validation sums carry their counts)"""
+        lo, hi = i * rays_per_image, (i + 1) * rays_per_image
+        per = -(-rays_per_image // world)
+        a, b = min(lo + rank * per, hi), min(lo + (rank + 1) * per, hi)
+        return {k: v[a:b] for k, v in self.t.items()}
+
     def steps_per_epoch(self, global_batch: int) -> int:
         return max(1, len(self) // global_batch)
 
@@ -78,8 +90,10 @@ class GpuRayBank:
         base = it * global_batch
         if shuffle:
             if self._perm_epoch != epoch or self._perm is None:
-                g = torch.Generator(device="cpu").manual_seed(self.seed * 1000003 + epoch)
-                self._perm = torch.randperm(len(self), generator=g).to(self.device)
+                # drawn ON the bank's device (no host randperm + upload per epoch); every rank seeds the same generator
+                # of the same device type, so all ranks hold the same permutation
+                g = torch.Generator(device=self.device).manual_seed(self.seed * 1000003 + epoch)
+                self._perm = torch.randperm(len(self), generator=g, device=self.device)
                 self._perm_epoch = epoch
             idx = self._perm[base + lo: base + hi]
         else:

@@ -144,6 +144,44 @@ class TrainLoop:
         return out
 
 
+    # ---- validation (pl.Trainer's val loop over val_dataloader(): framework/pipelines.py:120-129,316-318) ---------
+    @torch.no_grad()
+    def validate(self, rays_per_image: int = None, max_images: int = None):
+        """Every image of the `rgb_test` bank through pipeline.validation_step; returns the split's means (loss, PSNR,
+        semantic accuracy, per-image mIoU), the split-wide row-normalised confusion matrix and its mIoU
+        (eval/eval_semantic.py:63-77,122-140) -- one host read at the very end.  Ranks share each image's rays."""
+        pl = self.pipeline
+        bank = pl.datasets["rgb_test"]
+        hw = rays_per_image or min(len(bank), 64 * 64)
+        n = bank.n_images(hw)
+        if max_images is not None:
+            n = min(n, max_images)
+        acc, cm = {}, None
+        for i in range(n):
+            b = dict(bank.image(i, hw, self.rank, self.world), split="test")
+            out = pl.validation_step(b, i)
+            sse_cnt = torch.stack([out["sse"], out["count"]])
+            parallel.allreduce_sum_(sse_cnt)
+            vals = {"loss": out["loss"], "psnr": -10.0 * torch.log10(sse_cnt[0] / sse_cnt[1])}
+            if "confusion_counts" in out:
+                from ..semantic.components import metrics as M
+                c = parallel.allreduce_sum_(out["confusion_counts"].clone())
+                cm = c if cm is None else cm + c
+                vals["mIoU"] = M.semantic_mIoU(c).to(torch.float32)
+                vals["semantic_accuracy"] = torch.diagonal(c).sum() / c.sum()
+            for k, v in vals.items():
+                acc[k] = v if k not in acc else acc[k] + v
+        res = {f"test/{k}": float(v) / max(n, 1) for k, v in acc.items()}
+        if cm is not None:
+            from ..semantic.components import metrics as M
+            rows = cm.sum(dim=1, keepdim=True)
+            res["test/confusion_matrix"] = torch.where(rows > 0, cm / rows.clamp_min(1.0), torch.zeros_like(cm)).cpu()
+            res["test/mIoU_split"] = float(M.semantic_mIoU(cm))
+        for k, v in res.items():
+            if not torch.is_tensor(v):
+                pl.log(k, v)
+        return res
+
     # ---- checkpoints (Lightning layout; framework/util/load_ckpoint.py) ----------------------------------------
     def save_ckpoint(self, checkpoint_fp):
         from .util.load_ckpoint import save_ckpoint
@@ -165,13 +203,19 @@ class TrainLoop:
         return self.pipeline.train_steps
 
 
-def run_pipeline(pipeline, cfgs, device=None, max_steps=None, on_step=None):
-    """Training loop (replaces pl.Trainer.fit of framework/pipelines.py:238-331)."""
+def run_pipeline(pipeline, cfgs, device=None, max_steps=None, on_step=None, on_validation=None):
+    """Training loop (replaces pl.Trainer.fit of framework/pipelines.py:238-331): optimiser steps, and after every
+    `check_val_every_n_epoch`-th epoch the validation loop over the test images (:316-318)."""
     loop = TrainLoop(pipeline, cfgs, device)
     steps = max_steps if max_steps is not None else cfgs.run.max_train_steps
+    every = int(cfgs.run.check_val_every_n_epoch)
     t0 = time.time()
     for step in range(pipeline.train_steps, steps):
         out = loop.step(step)
         if on_step is not None:
             on_step(step, out)
+        if every > 0 and (step + 1) % loop.steps_per_epoch == 0 and ((step + 1) // loop.steps_per_epoch) % every == 0:
+            val = loop.validate()
+            if on_validation is not None:
+                on_validation(step, val)
     return time.time() - t0

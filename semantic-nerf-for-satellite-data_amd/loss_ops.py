@@ -99,7 +99,8 @@ class _FusedLoss(torch.autograd.Function):
         if sync and _dist_world() > 1:
             from .parallel import allreduce_sum_
             allreduce_sum_(totals)           # sums and counts over all ranks (tiny: 16 floats)
-            n_global = float(N) * _dist_world()  # equal shards per rank (the sampler guarantees it)
+            n_global = 0.0                   # = take the global ray count from totals (it is one of the summed counts):
+            #                                  right for unequal shards too (e.g. the depth-ray bank)
         grads = {k: (torch.empty_like(t[k], memory_format=torch.contiguous_format) if t[k] is not None else None)
                  for k in _DIFF}
         lg = _lib.SnerfLossGrads()

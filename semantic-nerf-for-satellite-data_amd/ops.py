@@ -14,8 +14,8 @@ import os
 
 from . import _lib
 
-# SNERF_MFMA=fp32 forces the plain fp32 matrix instruction; default is the split-bf16 form (same accuracy class)
-# SNERF_MFMA=fp32|split3|split2|bf16 overrides every ModelSpec.mfma (diagnostics, bench.py --mfma)
+# SNERF_MFMA=f16x2|split3|fp32|split3_bwd2|split2|bf16 overrides every ModelSpec.mfma (diagnostics, bench.py --mfma);
+# unset, ModelSpec.mfma decides and its default is f16x2 -- the arithmetic a C caller gets with no arithmetic flag
 BASE_FLAGS = _lib.MFMA_FLAGS.get(os.environ.get("SNERF_MFMA", "").lower())
 
 
@@ -236,6 +236,38 @@ def output_keys(spec: ModelSpec, sc_pass: bool) -> list:
     return keys
 
 
+# which parameter groups (state_dict name prefixes) and which embedding inputs a result's gradient can reach
+# (semantic/models/rs_semantic.py:260-340 data flow).  A group no incoming gradient reaches gets None from backward,
+# exactly as autograd leaves .grad = None in the reference -- torch.optim.Adam (and FlatAdam) then skip it.
+_TOUCH = {
+    "rgb": ("fc_net.", "sigma_from_xyz.", "feats_from_xyz.", "rgb_from_xyzdir.", "sun_v_net.", "sky_color."),
+    "depth": ("fc_net.", "sigma_from_xyz."), "weights": ("fc_net.", "sigma_from_xyz."),
+    "transparency": ("fc_net.", "sigma_from_xyz."), "sigmas": ("fc_net.", "sigma_from_xyz."),
+    "albedo": ("fc_net.", "feats_from_xyz.", "rgb_from_xyzdir."),
+    "sun": ("fc_net.", "feats_from_xyz.", "sun_v_net."),
+    "sky": ("sky_color.",),
+    "beta": ("fc_net.", "feats_from_xyz.", "beta_from_xyz."),
+    "beta_semantic": ("fc_net.", "feats_from_xyz.", "semantic_beta_from_xyz."),
+    "semantic_logits": ("fc_net.", "sigma_from_xyz.", "feats_from_xyz.", "semantic_prediction."),
+}
+
+
+def _touched(spec, live_keys):
+    """(set of parameter-name prefixes, t reached?, t_s reached?) for the results that received a gradient"""
+    groups = set()
+    for k in live_keys:
+        groups.update(_TOUCH[k])
+    sep = spec.n_classes > 0 and spec.use_separate_tj_for_semantic
+    t_users, ts_users = {"beta_from_xyz."}, set()
+    if spec.n_classes > 0 and spec.use_tj_instead_of_beta:
+        t_users.add("rgb_from_xyzdir.")
+    if spec.n_classes > 0 and spec.use_tj_for_s:
+        (ts_users if sep else t_users).add("semantic_prediction.")
+    if spec.n_classes > 0 and spec.use_separate_beta_for_s:
+        (ts_users if sep else t_users).add("semantic_beta_from_xyz.")
+    return groups, bool(groups & t_users), bool(groups & ts_users)
+
+
 class _RenderPass(torch.autograd.Function):
     """forward = snerf_forward, backward = snerf_backward (+ snerf_unpack_grads)."""
 
@@ -272,6 +304,7 @@ class _RenderPass(torch.autograd.Function):
         ctx.packed, ctx.names, ctx.keys, ctx.tc, ctx.tsc = packed, names, keys, tc, tsc
         ctx.param_like = params
         ctx.train = need_grad
+        ctx.set_materialize_grads(False)   # results the loss does not use arrive as None, not as zero tensors
         ret = tuple(outs[k] for k in keys)
         nd = [z_out] + ([label] if label is not None else [])
         ctx.mark_non_differentiable(*nd)
@@ -285,12 +318,16 @@ class _RenderPass(torch.autograd.Function):
             raise RuntimeError("snerf_amd: backward through a pass that was run without SNERF_FLAG_TRAIN")
         spec, d = ctx.spec, ctx.desc
         go = _lib.SnerfOutGrads()
-        keep = []
+        keep, live = [], []
         for k, g in zip(ctx.keys, gouts[:ctx.n_diff]):
             if g is not None:
                 g = g.contiguous()
                 keep.append(g)
+                live.append(k)
                 setattr(go, k, g.data_ptr())
+        if not live:
+            return (None,) * (8 + len(ctx.names))
+        groups, t_live, ts_live = _touched(spec, live)
         dev = ctx.tc.device
         pg = torch.zeros_like(ctx.packed)
         d_t = torch.empty_like(ctx.tc)
@@ -302,7 +339,8 @@ class _RenderPass(torch.autograd.Function):
         like = dict(zip(ctx.names, ctx.param_like))
         grads = unpack_grads(spec, pg, like)
         ctx.ws = None
-        return (None, None, None, None, None, None, d_t, d_ts) + tuple(grads[n] for n in ctx.names)
+        return (None, None, None, None, None, None, d_t if t_live else None, d_ts if ts_live else None) + tuple(
+            grads[n] if n.startswith(tuple(groups)) else None for n in ctx.names)
 
 
 def render_pass(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Tensor, t_s: torch.Tensor | None = None,

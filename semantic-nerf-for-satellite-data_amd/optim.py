@@ -53,7 +53,11 @@ class FlatAdam:
                 g = self.flat_g[o:o + p.numel()].view_as(p)
                 p.grad = g
                 self._gviews.append(g)
-        self.step_count = 0
+        # torch.optim.Adam counts steps PER PARAMETER and skips a parameter whose .grad is None: with the default
+        # first_beta_epoch = 2 the beta head and the transient embedding get no gradient during epochs 0-1, so their
+        # bias corrections start at step 1 when the beta loss switches on (baseline/components/training_step.py:22-28)
+        self.steps = [0] * len(self.params)
+        self._active = None
         self.param_groups = [{"lr": float(lr), "betas": tuple(betas), "eps": float(eps), "weight_decay": 0.0,
                               "amsgrad": False, "params": list(range(len(self.params)))}]
 
@@ -63,6 +67,7 @@ class FlatAdam:
         tensors without an add kernel per parameter, and step() gathers them into the flat buffer with one
         multi-tensor copy.  set_to_none=False: one memset, .grad stays a view of the flat buffer and autograd
         accumulates into it in place."""
+        self._active = None
         if set_to_none:
             for p in self.params:
                 p.grad = None
@@ -74,9 +79,14 @@ class FlatAdam:
 
     def _collect_foreign_grads(self):
         """Make flat_g hold every gradient: .grad tensors that are not views of it are gathered by one multi-tensor
-        copy (and re-pointed at their view); parameters without a gradient contribute zeros."""
-        src, dst = [], []
+        copy (and re-pointed at their view).  A parameter WITHOUT a gradient (autograd produced none since the last
+        zero_grad) is remembered as inactive for this step -- its slice of the bucket is zeroed so that the flat
+        all-reduce stays one call, and step() skips it as torch.optim.Adam does."""
+        if self._active is not None:      # already gathered for this step (TrainLoop calls this before the all-reduce)
+            return
+        src, dst, active = [], [], []
         for p, g in zip(self.params, self._gviews):
+            active.append(p.grad is not None)
             if p.grad is None:
                 g.zero_()
             elif p.grad.data_ptr() != g.data_ptr():
@@ -85,28 +95,59 @@ class FlatAdam:
             p.grad = g
         if src:
             torch._foreach_copy_(dst, src)
+        self._active = active
+
+    @property
+    def step_count(self):
+        """largest per-parameter step count (the shared count when every parameter has had a gradient every step)"""
+        return max(self.steps)
+
+    def _runs(self):
+        """maximal runs of consecutive ACTIVE parameters with equal step count -> (first, last+1); one launch each
+        (normally one run; two while a head is still waiting for its first gradient)"""
+        runs, i, n = [], 0, len(self.params)
+        while i < n:
+            if not self._active[i]:
+                i += 1
+                continue
+            j = i
+            while j + 1 < n and self._active[j + 1] and self.steps[j + 1] == self.steps[i]:
+                j += 1
+            runs.append((i, j + 1))
+            i = j + 1
+        return runs
 
     @torch.no_grad()
     def step(self, grad_scale: float = 1.0):
         self._collect_foreign_grads()
-        self.step_count += 1
         grp = self.param_groups[0]
         L = _lib.lib()
         st = torch.cuda.current_stream(self.flat_p.device).cuda_stream
-        _lib.check(L.snerf_adam_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-                                     self.exp_avg_sq.data_ptr(), C.c_ulonglong(self.numel), grp["lr"], grp["betas"][0],
-                                     grp["betas"][1], grp["eps"], self.step_count, float(grad_scale), C.c_void_p(st)),
-                   "snerf_adam_step")
+        esz = 4
+        for a, b in self._runs():
+            lo = self.offsets[a]
+            hi = self.offsets[b] if b < len(self.params) else self.numel
+            for i in range(a, b):
+                self.steps[i] += 1
+            _lib.check(L.snerf_adam_step(self.flat_p.data_ptr() + lo * esz, self.flat_g.data_ptr() + lo * esz,
+                                         self.exp_avg.data_ptr() + lo * esz, self.exp_avg_sq.data_ptr() + lo * esz,
+                                         C.c_ulonglong(hi - lo), grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"],
+                                         self.steps[a], float(grad_scale), C.c_void_p(st)), "snerf_adam_step")
+        self._active = None
 
     def state_dict(self):
+        """torch.optim.Adam's layout: state[i] exists only for parameters that have been stepped, each with its own
+        `step`"""
         state = {}
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            if self.steps[i] == 0:
+                continue
             n = p.numel()
-            state[i] = {"step": torch.tensor(float(self.step_count)),
+            state[i] = {"step": torch.tensor(float(self.steps[i])),
                         "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
                         "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
         groups = [dict(g, betas=tuple(g["betas"])) for g in self.param_groups]
-        return {"state": state if self.step_count > 0 else {}, "param_groups": groups}
+        return {"state": state, "param_groups": groups}
 
     @torch.no_grad()
     def load_state_dict(self, sd):
@@ -116,20 +157,21 @@ class FlatAdam:
             raise ValueError(f"FlatAdam: checkpoint holds {n_saved} parameters, the pipeline has {len(self.params)}")
         g0 = groups[0]
         self.param_groups[0].update(lr=float(g0["lr"]), betas=tuple(g0["betas"]), eps=float(g0["eps"]))
-        steps = set()
-        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-            s = sd["state"].get(i)
-            if s is None:
+        ids = [i for g in groups for i in g["params"]]     # torch numbers the parameters group by group
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for k, (p, o) in enumerate(zip(self.params, self.offsets)):
+            s = sd["state"].get(ids[k])
+            if s is None:                  # never stepped when the checkpoint was written (no gradient yet)
+                self.steps[k] = 0
                 continue
             n = p.numel()
             if tuple(s["exp_avg"].shape) != tuple(p.shape):
-                raise ValueError(f"FlatAdam: state {i} has shape {tuple(s['exp_avg'].shape)}, parameter {tuple(p.shape)}")
+                raise ValueError(f"FlatAdam: state {ids[k]} has shape {tuple(s['exp_avg'].shape)}, parameter {tuple(p.shape)}")
             self.exp_avg[o:o + n].view_as(p).copy_(s["exp_avg"])
             self.exp_avg_sq[o:o + n].view_as(p).copy_(s["exp_avg_sq"])
-            steps.add(int(float(s["step"])))
-        if len(steps) > 1:
-            raise ValueError("FlatAdam: per-parameter step counts differ; one shared count is supported")
-        self.step_count = steps.pop() if steps else 0
+            self.steps[k] = int(float(s["step"]))
+        self._active = None
 
 
 class StepLR:

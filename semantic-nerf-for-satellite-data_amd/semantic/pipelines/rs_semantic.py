@@ -56,6 +56,29 @@ class RSSemanticPipeline(SatNeRFPipeline):
     def _init_training_step(self):
         return RSSemanticTrainingStep()
 
+    # ---- validation: the base step plus the semantic metrics of eval/eval_semantic.py:66-100, on the device -------
+    def _val_result_keys(self):
+        return super()._val_result_keys() + ["semantic_label_coarse"]
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx):
+        """adds semantic_accuracy, the (C, C) confusion COUNTS of this image (rows = ground truth; the caller sums them
+        over the split -- eval_semantic.py:63,75-77 -- and over ranks), mIoU of this image and, when the image has car
+        rays, the composited uncertainty at the transient class."""
+        from ..components import metrics as M
+        out = super().validation_step(batch, batch_idx)
+        res = out["results"]
+        gt = batch["semantic"].reshape(-1, 1)
+        n_cls = self.datasets["rgb"].semantic_n_classes
+        out["semantic_accuracy"] = M.semantic_accuracy(res, gt)
+        out["confusion_counts"] = M.confusion_matrix_values(res, gt, n_cls, normalize=None)
+        out["mIoU"] = M.semantic_mIoU(out["confusion_counts"])
+        out["uncertainty_at_transient"] = M.uncertainty_at_transient(res, gt, self.datasets["rgb"].car_cls_idx)
+        if batch.get("split", "test") == "test":
+            self.log("test/semantic_accuracy", out["semantic_accuracy"], batch_size=1)
+            self.log("test/mIoU", out["mIoU"], batch_size=1)
+        return out
+
     @classmethod
     def init_config(cls, cfg_information):
         return RSSemanticConfig(**cfg_information)

@@ -54,13 +54,18 @@ def test_host_only_sizes_and_errors():
     bad = ModelSpec(fc_units=520).desc(16, 8)
     assert L.snerf_packed_floats(C.byref(bad)) == 0
     assert b"fc_units" in L.snerf_last_error()
-    # arithmetic flags are exclusive: fp16 planes with any of the bf16 / fp32-instruction flags is refused
-    for other in (_lib.FLAG_FP32_MFMA, _lib.FLAG_BF16, _lib.FLAG_BF16X3, _lib.FLAG_BWD_BF16X3):
-        bad = ModelSpec(mfma="split3").desc(16, 8, _lib.FLAG_F16X2 | other)
-        assert L.snerf_workspace_bytes(C.byref(bad)) == 0
-        assert b"SNERF_FLAG_F16X2" in L.snerf_last_error()
-    bad = ModelSpec(mfma="split3").desc(16, 8, _lib.FLAG_FP32_MFMA | _lib.FLAG_BF16)
-    assert L.snerf_workspace_bytes(C.byref(bad)) == 0
+    # arithmetic flags are exclusive (flags = 0 is the default arithmetic, f16x2); split3_bwd2 may name its forward mode
+    sel = (_lib.FLAG_F16X2, _lib.FLAG_SPLIT3, _lib.FLAG_FP32_MFMA, _lib.FLAG_BF16, _lib.FLAG_BF16X3, _lib.FLAG_BWD_BF16X3)
+    for a in sel:
+        for b in sel:
+            d = ModelSpec().desc(16, 8, a | b)
+            ok = a == b or {a, b} == {_lib.FLAG_SPLIT3, _lib.FLAG_BWD_BF16X3}
+            assert (L.snerf_workspace_bytes(C.byref(d)) != 0) == ok, (a, b)
+            if not ok:
+                assert b"arithmetic flag" in L.snerf_last_error()
+    # the default arithmetic is the same object for a C caller (flags = 0) and for Python's ModelSpec()
+    assert L.snerf_workspace_bytes(C.byref(ModelSpec().desc(64, 8))) == L.snerf_workspace_bytes(C.byref(ModelSpec().desc(64, 8, _lib.FLAG_F16X2)))
+    assert L.snerf_version() == 2
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -256,10 +256,12 @@ def test_backward_matches_oracle_and_golden(name):
     assert n >= 20
 
 
-def test_full_width_forward_backward():
-    """W=512, S=64 (the headline architecture) on the 16-ray golden case: per-ray outputs, losses, grad norms."""
+@pytest.mark.parametrize("name", ["sem_siren_full", "satnerf_full_c1"])
+def test_full_width_forward_backward(name):
+    """W=512 (the headline architecture; S=64 semantic, and BASELINE configs[0]'s baseline SatNeRF at S=32) on the 16-ray
+    golden cases written by the reference itself: per-ray outputs, losses, grad norms."""
     dev = _dev()
-    z, meta, cfg = load_fixture("sem_siren_full")
+    z, meta, cfg = load_fixture(name)
     pn = fixture_params(z, meta, cfg)
     b = fixture_batch(z)
     gp = _gpu_params(pn, dev, requires_grad=True)
@@ -340,7 +342,7 @@ def test_reduced_precision_modes_full_width(monkeypatch):
     b = fixture_batch(z)
     grads = {}
     outs = {}
-    for name, flags, out_tol, loss_tol in (("split3", 0, OUT_TOL, 2e-4), ("split2", _lib.FLAG_BF16X3, 1e-4, 2e-4),
+    for name, flags, out_tol, loss_tol in (("split3", _lib.FLAG_SPLIT3, OUT_TOL, 2e-4), ("split2", _lib.FLAG_BF16X3, 1e-4, 2e-4),
                                            ("bf16", _lib.FLAG_BF16, 2e-2, 1e-2),
                                            ("split3_bwd2", _lib.FLAG_BWD_BF16X3, OUT_TOL, 2e-4)):
         monkeypatch.setattr(ops, "BASE_FLAGS", flags)
@@ -368,7 +370,7 @@ def test_reduced_precision_modes_full_width(monkeypatch):
 
 
 def test_fp32_mfma_flag_path(monkeypatch):
-    """SNERF_FLAG_FP32_MFMA (plain v_mfma_f32_32x32x2_f32 kernels) gives the same results as the default split-bf16 path"""
+    """SNERF_FLAG_FP32_MFMA (plain v_mfma_f32_32x32x2_f32 kernels) gives the same results as the split-bf16 (split3) path"""
     from snerf_amd import ops, _lib
     dev = _dev()
     z, meta, cfg = load_fixture("sem_siren_small")
@@ -376,7 +378,7 @@ def test_fp32_mfma_flag_path(monkeypatch):
     b = fixture_batch(z)
     emb = torch.from_numpy(O.init_embedding_numpy(cfg, meta["seed"]))
     outs = {}
-    for name, flags in (("x6", 0), ("fp32", _lib.FLAG_FP32_MFMA)):
+    for name, flags in (("x6", _lib.FLAG_SPLIT3), ("fp32", _lib.FLAG_FP32_MFMA)):
         monkeypatch.setattr(ops, "BASE_FLAGS", flags)
         gp = _gpu_params(pn, dev, requires_grad=True)
         emb_g = emb.clone().to(dev).requires_grad_(True)

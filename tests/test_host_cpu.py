@@ -18,8 +18,8 @@ def test_mfma_mode_mapping():
         assert ops.mfma_mode(NS(precision=32, mfma_precision="auto"), NS(float32_matmul_precision=run)) == want
     d = ops.ModelSpec(mfma="split2").desc(16, 8)
     assert d.flags & _lib.FLAG_BF16X3
-    assert ops.ModelSpec().desc(16, 8).flags == _lib.FLAG_F16X2          # default: fp32-class on fp16 planes
-    assert ops.ModelSpec(mfma="split3").desc(16, 8).flags == 0
+    assert ops.ModelSpec().desc(16, 8).flags == 0                        # default: no arithmetic bit = f16x2 (C callers too)
+    assert ops.ModelSpec(mfma="split3").desc(16, 8).flags == _lib.FLAG_SPLIT3
 
 import torch
 
@@ -169,40 +169,45 @@ def test_checkpoint_utilities_cpu(tmp_path):
 def test_validation_metrics_match_reference_definitions():
     """semantic_error / accuracy (filter_idx rows count as right, denominator = all rays), row-normalised confusion
     matrix, mIoU with nanmean over absent classes, beta-at-transient, masked PSNR -- against plain numpy restatements
-    of semantic/components/metrics.py:11-87 and eval/utils/metrics.py:8-18."""
-    import numpy as np
-    import torch
-    from snerf_amd.semantic.components import metrics as M
-    from snerf_amd.eval.utils.metrics import mse, psnr
-    rng = np.random.default_rng(5)
-    N, S, Cn = 500, 8, 6                       # class 5 never occurs: NaN IoU -> skipped
-    gt = rng.integers(0, 5, size=(N, 1)).astype(np.uint8)
-    pred = np.where(rng.random(N) < 0.7, gt[:, 0], rng.integers(0, 5, size=N)).astype(np.int64)
-    res = {"semantic_label_coarse": torch.from_numpy(pred), "rgb_coarse": torch.zeros(N, 3),
-           "weights_coarse": torch.from_numpy(rng.random((N, S)).astype(np.float32)),
-           "beta_coarse": torch.from_numpy(rng.random((N, S, 1)).astype(np.float32))}
-    tg = torch.from_numpy(gt)
-    err = (gt[:, 0] != pred).astype(np.float32)
-    assert abs(float(M.semantic_accuracy(res, tg)) - (1 - err.sum() / N)) < 1e-6
-    err4 = np.where(gt[:, 0] == 4, 0.0, err)
-    assert abs(float(M.semantic_accuracy(res, tg, filter_idx=4)) - (1 - err4.sum() / N)) < 1e-6
-    assert M.semantic_error(res["semantic_label_coarse"], tg).shape == tg.shape
-    counts = np.zeros((Cn, Cn))
-    for g, p in zip(gt[:, 0], pred):
-        counts[g, p] += 1
-    cm_counts = M.confusion_matrix_values(res, tg, Cn, normalize=None).numpy()
-    assert np.array_equal(cm_counts, counts)
-    cm = M.confusion_matrix_values(res, tg, Cn).numpy()
-    rows = counts.sum(1, keepdims=True)
-    assert np.allclose(cm, np.divide(counts, rows, out=np.zeros_like(counts), where=rows > 0), atol=1e-6)
-    ious = np.array([counts[c, c] / (counts[c].sum() + counts[:, c].sum() - counts[c, c]) if
-                     (counts[c].sum() + counts[:, c].sum()) > 0 else np.nan for c in range(Cn)])
-    assert abs(float(M.semantic_mIoU(cm_counts)) - np.nanmean(ious)) < 1e-9
-    w, b = res["weights_coarse"].numpy(), res["beta_coarse"].numpy()
-    comp = (w[..., None] * b).sum(-2)[:, 0]
-    car = gt[:, 0] == 3
-    assert abs(float(M.uncertainty_at_transient(res, tg, 3)) - comp[car].sum() / car.sum()) < 1e-5
-    a, c = torch.rand(40, 3), torch.rand(40, 3)
-    mask = torch.rand(40) > 0.5
-    assert abs(float(psnr(a, c, mask)) - float(-10 * torch.log10(((a - c) ** 2)[mask].mean()))) < 1e-6
-    assert mse(a, c, reduction="none").shape == (40, 3)
+    of semantic/components/metrics.py:11-87 and eval/utils/metrics.py:8-18 (tests/helpers.py; the GPU twin is
+    tests/test_gpu_rows.py::test_validation_metrics_on_device)."""
+    from tests.helpers import check_validation_metrics
+    check_validation_metrics("cpu")
+
+
+def test_siren_init_ranges():
+    """baseline/models/commons.py:5-18 as applied by rs_semantic.py:239-243 / satnerf.py:140-160: trunk and sun-visibility
+    weights ~ U(+-sqrt(6 / fan_in)), their first layers ~ U(+-1 / fan_in); biases and every other head keep PyTorch's
+    default Linear init (|.| <= 1 / sqrt(fan_in))."""
+    import math
+    from snerf_amd.framework.configs import MainConfig
+    from snerf_amd.framework.pipelines import load_pipeline
+    torch.manual_seed(3)
+    cfgs = MainConfig(run={"synthetic_rays": 256}, pipeline={"pipeline": "snerf_amd.semantic.pipelines.rs_semantic.RSSemanticPipeline",
+                                                             "fc_units": 128, "batch_size": 64, "depth_enabled": False})
+    m = load_pipeline(cfgs).model_coarse
+    for seq in (m.fc_net, m.sun_v_net):
+        first = True
+        for layer in seq:
+            if not isinstance(layer, torch.nn.Linear):
+                continue
+            n = layer.weight.shape[1]
+            bound = 1.0 / n if first else math.sqrt(6.0 / n)
+            w = layer.weight.detach()
+            assert float(w.abs().max()) <= bound * (1 + 1e-6), (n, first)
+            if w.numel() >= 4096:     # the range is actually used (uniform: max close to the bound, std = bound / sqrt(3))
+                assert float(w.abs().max()) >= 0.98 * bound and abs(float(w.std()) - bound / math.sqrt(3)) <= 0.03 * bound
+            assert float(layer.bias.detach().abs().max()) <= 1.0 / math.sqrt(n) + 1e-6
+            first = False
+    for head in (m.rgb_from_xyzdir, m.semantic_prediction, m.beta_from_xyz, m.sky_color):
+        for layer in head:
+            if isinstance(layer, torch.nn.Linear):
+                n = layer.weight.shape[1]
+                assert float(layer.weight.detach().abs().max()) <= 1.0 / math.sqrt(n) + 1e-6
+    # relu networks keep the default init everywhere (the sine initialisers are only applied for siren)
+    cfgs = MainConfig(run={"synthetic_rays": 256}, pipeline={"pipeline": "snerf_amd.semantic.pipelines.rs_semantic.RSSemanticPipeline",
+                                                             "fc_units": 128, "batch_size": 64, "depth_enabled": False,
+                                                             "activation_function": "relu"})
+    m = load_pipeline(cfgs).model_coarse
+    w = m.fc_net[2].weight.detach()
+    assert float(w.abs().max()) <= 1.0 / math.sqrt(w.shape[1]) + 1e-6
