@@ -236,38 +236,6 @@ def output_keys(spec: ModelSpec, sc_pass: bool) -> list:
     return keys
 
 
-# which parameter groups (state_dict name prefixes) and which embedding inputs a result's gradient can reach
-# (semantic/models/rs_semantic.py:260-340 data flow).  A group no incoming gradient reaches gets None from backward,
-# exactly as autograd leaves .grad = None in the reference -- torch.optim.Adam (and FlatAdam) then skip it.
-_TOUCH = {
-    "rgb": ("fc_net.", "sigma_from_xyz.", "feats_from_xyz.", "rgb_from_xyzdir.", "sun_v_net.", "sky_color."),
-    "depth": ("fc_net.", "sigma_from_xyz."), "weights": ("fc_net.", "sigma_from_xyz."),
-    "transparency": ("fc_net.", "sigma_from_xyz."), "sigmas": ("fc_net.", "sigma_from_xyz."),
-    "albedo": ("fc_net.", "feats_from_xyz.", "rgb_from_xyzdir."),
-    "sun": ("fc_net.", "feats_from_xyz.", "sun_v_net."),
-    "sky": ("sky_color.",),
-    "beta": ("fc_net.", "feats_from_xyz.", "beta_from_xyz."),
-    "beta_semantic": ("fc_net.", "feats_from_xyz.", "semantic_beta_from_xyz."),
-    "semantic_logits": ("fc_net.", "sigma_from_xyz.", "feats_from_xyz.", "semantic_prediction."),
-}
-
-
-def _touched(spec, live_keys):
-    """(set of parameter-name prefixes, t reached?, t_s reached?) for the results that received a gradient"""
-    groups = set()
-    for k in live_keys:
-        groups.update(_TOUCH[k])
-    sep = spec.n_classes > 0 and spec.use_separate_tj_for_semantic
-    t_users, ts_users = {"beta_from_xyz."}, set()
-    if spec.n_classes > 0 and spec.use_tj_instead_of_beta:
-        t_users.add("rgb_from_xyzdir.")
-    if spec.n_classes > 0 and spec.use_tj_for_s:
-        (ts_users if sep else t_users).add("semantic_prediction.")
-    if spec.n_classes > 0 and spec.use_separate_beta_for_s:
-        (ts_users if sep else t_users).add("semantic_beta_from_xyz.")
-    return groups, bool(groups & t_users), bool(groups & ts_users)
-
-
 class _RenderPass(torch.autograd.Function):
     """forward = snerf_forward, backward = snerf_backward (+ snerf_unpack_grads)."""
 
@@ -327,7 +295,6 @@ class _RenderPass(torch.autograd.Function):
                 setattr(go, k, g.data_ptr())
         if not live:
             return (None,) * (8 + len(ctx.names))
-        groups, t_live, ts_live = _touched(spec, live)
         dev = ctx.tc.device
         pg = torch.zeros_like(ctx.packed)
         d_t = torch.empty_like(ctx.tc)
@@ -339,8 +306,11 @@ class _RenderPass(torch.autograd.Function):
         like = dict(zip(ctx.names, ctx.param_like))
         grads = unpack_grads(spec, pg, like)
         ctx.ws = None
-        return (None, None, None, None, None, None, d_t if t_live else None, d_ts if ts_live else None) + tuple(
-            grads[n] if n.startswith(tuple(groups)) else None for n in ctx.names)
+        # EVERY parameter gets a gradient tensor, zero where no result gradient reaches it: the reference's model returns
+        # one concatenated (P, 9 + C) tensor that inference() slices (semantic/models/rs_semantic.py:71-96), so autograd
+        # hands e.g. the beta head exact ZEROS (not None) while epoch < first_beta_epoch, and torch.optim.Adam counts
+        # those steps (probed on the reference: 45 of 45 parameters have state after one step at epoch 0)
+        return (None, None, None, None, None, None, d_t, d_ts) + tuple(grads[n] for n in ctx.names)
 
 
 def render_pass(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Tensor, t_s: torch.Tensor | None = None,

@@ -53,9 +53,10 @@ class FlatAdam:
                 g = self.flat_g[o:o + p.numel()].view_as(p)
                 p.grad = g
                 self._gviews.append(g)
-        # torch.optim.Adam counts steps PER PARAMETER and skips a parameter whose .grad is None: with the default
-        # first_beta_epoch = 2 the beta head and the transient embedding get no gradient during epochs 0-1, so their
-        # bias corrections start at step 1 when the beta loss switches on (baseline/components/training_step.py:22-28)
+        # torch.optim.Adam counts steps PER PARAMETER and skips a parameter whose .grad is None; FlatAdam keeps the same
+        # bookkeeping so that optimizer_states written by either side load into the other.  (In the pipelines every
+        # parameter has a gradient every step -- the reference's concatenated model output makes autograd hand unused
+        # heads exact zeros, not None -- so all counts are equal there and the update is one launch.)
         self.steps = [0] * len(self.params)
         self._active = None
         self.param_groups = [{"lr": float(lr), "betas": tuple(betas), "eps": float(eps), "weight_decay": 0.0,
