@@ -275,6 +275,14 @@ int snerf_profile_end(SnerfProfile* out);
  * 1: stored (K, rows) row-contiguous.  Exposed so tests can check the MFMA tiling in isolation. */
 int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, int b_ic,
                     float* C, int ldc, int I, int J, int K, int narrow, void* stream);
+/* test hooks of the block-scaled fp16-plane kernels (csrc/bsp.h): fp32 in / fp32 out around one launch; synchronous and
+ * allocating -- tests only */
+int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int col0, float* dst, int* exps_out, void* stream);
+int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, const float* bias, int I, int J, int K, int a_col0,
+                      int c_col0, int act, float w0, int aux_mode, const float* Hact, const unsigned* Hsign, float* C,
+                      unsigned* Csign, float* colsum, int narrow, void* stream);
+int snerf_test_bsp_dw(const float* A, int lda_src, const float* B, int ldb_src, int P, int I, int J, int a_col0, int b_col0,
+                      int k_split, int narrow_i, float* C, void* stream);
 
 #ifdef __cplusplus
 }

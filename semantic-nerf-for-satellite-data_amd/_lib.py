@@ -130,6 +130,15 @@ def lib():
     L.snerf_test_gemm.restype = C.c_int
     L.snerf_test_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.snerf_test_bsp_roundtrip.restype = C.c_int
+    L.snerf_test_bsp_roundtrip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.snerf_test_bsp_kc.restype = C.c_int
+    L.snerf_test_bsp_kc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_void_p]
+    L.snerf_test_bsp_dw.restype = C.c_int
+    L.snerf_test_bsp_dw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.snerf_loss_workspace_bytes.restype = C.c_size_t
     L.snerf_loss_workspace_bytes.argtypes = [C.POINTER(SnerfLossCfg)]
     L.snerf_loss_partial.restype = C.c_int
@@ -160,4 +169,5 @@ def check(rc, what):
 EXPORTED_SYMBOLS = ("snerf_version", "snerf_last_error", "snerf_packed_floats", "snerf_workspace_bytes",
                     "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward", "snerf_test_gemm",
                     "snerf_loss_workspace_bytes", "snerf_loss_partial", "snerf_loss_finish", "snerf_profile_begin",
-                    "snerf_profile_end", "snerf_sample_z", "snerf_adam_step")
+                    "snerf_profile_end", "snerf_sample_z", "snerf_adam_step", "snerf_test_bsp_roundtrip", "snerf_test_bsp_kc",
+                    "snerf_test_bsp_dw")

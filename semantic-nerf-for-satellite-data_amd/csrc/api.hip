@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "aux_kernels.h"
+#include "bsp.h"
 #include "composite.h"
 #include "gemm.h"
 #include "plan.h"
@@ -568,6 +569,16 @@ static int check_inputs(const Plan& p, const SnerfInputs* in) {
 // =====================================================================================================
 using namespace snerf;
 
+namespace {
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? 0 : 1; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+#define TALLOC(buf, bytes) do { if ((buf).alloc(bytes)) { set_error("test hook: hipMalloc failed"); return SNERF_ERR_HIP; } } while (0)
+}  // namespace
+
 extern "C" {
 
 int snerf_version(void) { return SNERF_ABI_VERSION; }
@@ -691,6 +702,92 @@ int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, 
     g.fmt = 1; g.planes = 2; g.x6 = true; g.a_max = slots; g.b_max = slots + 64;
   }
   return launch_gemm(g, (hipStream_t)stream);
+}
+
+// ---- test hooks of the block-scaled plane kernels (tests/test_gpu_bsp.py): fp32 in / fp32 out around ONE launch of the
+// kernel under test; the conversions run through the library's own to_planes / from_planes / weight pack.  Synchronous,
+// allocating -- never on the product path.
+
+int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int col0, float* dst, int* exps_out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  DevBuf pl, E;
+  const size_t rp = round_up_sz(rows, 128);
+  TALLOC(pl, bsp::plane_bytes(rp, ld)); TALLOC(E, bsp::etab_ints(rp, ld) * 4);
+  SNERF_HIP_CHECK(hipMemsetAsync(E.p, 0, bsp::etab_ints(rp, ld) * 4, st));
+  RC(bsp::launch_to_planes(src, cols, rows, cols, pl.as<char>(), E.as<int>(), ld, col0, st));
+  RC(bsp::launch_from_planes(pl.as<char>(), E.as<int>(), ld, col0, rows, cols, dst, cols, st));
+  if (exps_out) SNERF_HIP_CHECK(hipMemcpyAsync(exps_out, E.p, bsp::etab_ints(rp, ld) * 4, hipMemcpyDeviceToDevice, st));
+  SNERF_HIP_CHECK(hipStreamSynchronize(st));
+  return SNERF_OK;
+}
+
+// C[I][J] = epilogue(A[I][Ka] | A2[I][K-Ka]) . W[J][K]^T).  The A tensors are placed at column a_col0 of wider plane
+// tensors and the output at column c_col0 (exercises the column-offset / exponent-block arithmetic).
+int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, const float* bias, int I, int J, int K, int a_col0,
+                      int c_col0, int act, float w0, int aux_mode, const float* Hact, const unsigned* Hsign, float* C,
+                      unsigned* Csign, float* colsum, int narrow, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (K % 16 || Ka % 16 || Ka <= 0 || Ka > K) { set_error("test_bsp_kc: K, Ka % 16"); return SNERF_ERR_BAD_DESC; }
+  const size_t rp = round_up_sz(I, 128);
+  const int lda = a_col0 + Ka, lda2 = K > Ka ? K - Ka : 16, ldc = c_col0 + round_up(J, 16);
+  DevBuf pa, ea, pa2, ea2, wp, we, wm, pc, ec, ph, eh;
+  TALLOC(pa, bsp::plane_bytes(rp, lda)); TALLOC(ea, bsp::etab_ints(rp, lda) * 4);
+  TALLOC(pa2, bsp::plane_bytes(rp, lda2)); TALLOC(ea2, bsp::etab_ints(rp, lda2) * 4);
+  RC(bsp::launch_to_planes(A, Ka, I, Ka, pa.as<char>(), ea.as<int>(), lda, a_col0 & ~127, st));
+  if (a_col0 & 127) { set_error("test_bsp_kc: a_col0 % 128"); return SNERF_ERR_BAD_DESC; }
+  if (K > Ka) RC(bsp::launch_to_planes(A2, K - Ka, I, K - Ka, pa2.as<char>(), ea2.as<int>(), lda2, 0, st));
+  bsp::WPackTable tb; tb.n = 1;
+  tb.j[0] = bsp::WPackJob{0ull, K, J, K, 0, 0ull, 0, J, K};
+  TALLOC(wp, bsp::wp16_bytes(J, K)); TALLOC(we, bsp::WPACK_MAX * 4); TALLOC(wm, bsp::WPACK_MAX * 4);
+  RC(bsp::launch_wpack(tb, W, wp.as<char>(), we.as<int>(), wm.as<unsigned>(), st));
+  bsp::KcArgs g;
+  g.A = pa.as<char>(); g.EA = ea.as<int>(); g.lda = lda; g.a_col0 = a_col0; g.Ka = Ka;
+  if (K > Ka) { g.A2 = pa2.as<char>(); g.EA2 = ea2.as<int>(); g.lda2 = lda2; g.a2_col0 = 0; }
+  g.W = wp.as<char>(); g.EW = we.as<int>(); g.w_rb32 = (J + 31) / 32; g.w_bytes = (unsigned)bsp::wp16_bytes(J, K);
+  g.I = I; g.J = J; g.K = K; g.bias = bias; g.act = act; g.w0 = w0;
+  if (narrow) {
+    g.Cf = C;
+    RC(bsp::launch_kc_narrow(g, st));
+    SNERF_HIP_CHECK(hipStreamSynchronize(st));
+    return SNERF_OK;
+  }
+  TALLOC(pc, bsp::plane_bytes(rp, ldc)); TALLOC(ec, bsp::etab_ints(rp, ldc) * 4);
+  g.C = pc.as<char>(); g.EC = ec.as<int>(); g.ldc = ldc; g.c_col0 = c_col0; g.Csign = Csign;
+  if (aux_mode != AUX_NONE) {
+    TALLOC(ph, bsp::plane_bytes(rp, ldc)); TALLOC(eh, bsp::etab_ints(rp, ldc) * 4);
+    RC(bsp::launch_to_planes(Hact, J, I, J, ph.as<char>(), eh.as<int>(), ldc, c_col0, st));
+    g.aux_mode = aux_mode; g.H = ph.as<char>(); g.EH = eh.as<int>(); g.ldh = ldc; g.h_col0 = c_col0; g.Hsign = Hsign;
+  }
+  g.colsum = colsum; g.ldcs = J;
+  RC(bsp::launch_kc(g, st));
+  RC(bsp::launch_from_planes(pc.as<char>(), ec.as<int>(), ldc, c_col0, I, J, C, J, st));
+  SNERF_HIP_CHECK(hipStreamSynchronize(st));
+  return SNERF_OK;
+}
+
+// C[I][J] = sum_p A[p][a_col0 + i] B[p][b_col0 + j] through split-K slabs + the library's deterministic slab reduction
+int snerf_test_bsp_dw(const float* A, int lda_src, const float* B, int ldb_src, int P, int I, int J, int a_col0, int b_col0,
+                      int k_split, int narrow_i, float* C, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const size_t rp = round_up_sz(P, 128);
+  const int lda = round_up(lda_src, 16), ldb = round_up(ldb_src, 16);
+  DevBuf pa, ea, pb, eb, slab, tmp;
+  TALLOC(pa, bsp::plane_bytes(rp, lda)); TALLOC(ea, bsp::etab_ints(rp, lda) * 4);
+  TALLOC(pb, bsp::plane_bytes(rp, ldb)); TALLOC(eb, bsp::etab_ints(rp, ldb) * 4);
+  RC(bsp::launch_to_planes(A, lda_src, P, lda_src, pa.as<char>(), ea.as<int>(), lda, 0, st));
+  RC(bsp::launch_to_planes(B, ldb_src, P, ldb_src, pb.as<char>(), eb.as<int>(), ldb, 0, st));
+  const int ns = (P + k_split - 1) / k_split;
+  const size_t stride = round_up_sz((size_t)I * J, 64);
+  TALLOC(slab, stride * ns * 4); TALLOC(tmp, 64 * stride * 4);
+  bsp::DwArgs g;
+  g.A = pa.as<char>(); g.EA = ea.as<int>(); g.lda = lda; g.a_col0 = a_col0;
+  g.B = pb.as<char>(); g.EB = eb.as<int>(); g.ldb = ldb; g.b_col0 = b_col0;
+  g.I = I; g.J = J; g.P = P; g.C = slab.as<float>(); g.ldc = J; g.k_split = k_split; g.n_split = ns; g.slab_stride = stride;
+  RC(bsp::launch_dw(g, narrow_i != 0, st));
+  SNERF_HIP_CHECK(hipMemsetAsync(C, 0, (size_t)I * J * 4, st));
+  RC(reduce_partials(slab.as<float>(), ns, stride, I * J, tmp.as<float>(), C, st));
+  SNERF_HIP_CHECK(hipStreamSynchronize(st));
+  return SNERF_OK;
 }
 
 }  // extern "C"

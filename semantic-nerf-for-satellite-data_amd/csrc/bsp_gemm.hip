@@ -1,0 +1,660 @@
+// GEMMs on block-scaled fp16-plane tensors (bsp.h) for gfx950: the dense layers of the default arithmetic.
+//
+//   gemm_kc_kernel   C = epilogue(A W^T): forward layers and dX.  128 x 256 tile, four waves of 64 x 128, two workgroups per CU.
+//   gemm_kcn_kernel  the same contraction for the 32-wide head outputs (sigma, sun visibility, final head layers): fp32 out.
+//   gemm_dw_kernel   dW = dZ^T X over all points, split-K slabs.  256 x 256 tile, eight waves of 128 x 64, one workgroup per CU
+//                    (and a 32 x 256 form for the 32-wide heads).
+//
+// Operand staging is LDS-DMA only (buffer_load_dwordx4 ... lds): the planes are already what the matrix cores eat, so a
+// k-step moves bytes and nothing else -- no VGPR staging, no conversion, no LDS stores.  Ring of three 16-deep stages;
+// stage s + 2 is requested right after the barrier that publishes stage s, a counted s_waitcnt vmcnt(N) (never 0 in the
+// loop) leaves it in flight across that barrier.  The LDS image is lane-linear as the DMA requires; bank-conflict
+// swizzles are applied on the per-lane SOURCE address and again on the fragment read (same involution).
+//   K-contiguous operands: [row][64 B] = chunks {hi k0-7, hi k8-15, lo k0-7, lo k8-15}, chunk position ^= (row >> 2) & 3:
+//     every 16-lane group of the ds_read_b128 fragment read covers all 64 banks.
+//   Point-contiguous operands (dW): [16 points][1 KiB] = 256 columns of one point, byte ^= ((p & 1) << 5) | ((p & 2) << 6):
+//     the four point rows of a ds_read_b64_tr_b16 block land in four different bank quarters.
+// Exponents: one per (128-row, 128-column) block of a tensor.  The accumulators carry the scale of the block being
+// contracted; where it changes along k they are multiplied by the power of two (v_ldexp, exact).  In a SIREN forward
+// pass every block of an activation has its maximum in [0.5, 1], so the branch is never taken.
+#include "bsp.h"
+#include "gemm_common.h"
+
+#include <vector>
+
+namespace snerf {
+namespace bsp {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(srd_t srd, char* lds_dst, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void barrier_raw() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+__device__ __forceinline__ f32x16 scale_acc(f32x16 c, int de) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) c[r] = __builtin_amdgcn_ldexpf(c[r], de);
+  return c;
+}
+__device__ __forceinline__ f16x8 ldsfrag(const char* p) { return *reinterpret_cast<const f16x8*>(p); }
+
+// three fp16 products per fp32 product, smallest terms first
+__device__ __forceinline__ f32x16 mfma3(f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+  return c;
+}
+
+// exponent of k-step s of a K-contiguous A operand made of one or two segments (any lane; uniform inputs)
+__device__ __forceinline__ int kc_exp_of_step(const KcArgs& p, int rb, int s, int nks1) {
+  const bool seg2 = s >= nks1;   // branch-free: one load through a selected pointer
+  const int* E = seg2 ? p.EA2 : p.EA;
+  const int ld = seg2 ? p.lda2 : p.lda, col = seg2 ? p.a2_col0 + 16 * (s - nks1) : p.a_col0 + 16 * s;
+  return E[(size_t)rb * ncb_of(ld) + (col >> 7)];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K-contiguous GEMM, BSP output
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int KC_A = 128 * 64, KC_B = 256 * 64, KC_STAGE = KC_A + KC_B, KC_RING = 3;
+constexpr int KC_STRIP = 32 * 68 * 4;                      // one wave's 32 x (64 + 4) fp32 transposition strip
+constexpr int KC_TAIL = KC_RING * KC_STAGE;                // small tables behind the ring
+constexpr int KC_LDS = KC_TAIL + 128 * 4 + 64;
+
+template <int ACT, int AUX, bool COLSUM>
+__global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[KC_LDS];
+  int* etab = reinterpret_cast<int*>(lds + KC_TAIL);
+  float* smax = reinterpret_cast<float*>(lds + KC_TAIL + 512);
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int wi0 = wr * 64, wj0 = wc * 128;
+  int ti, tj;
+  tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);
+  const int i0 = ti * 128, j0 = tj * 256;
+  const int nks = p.K >> 4, nks1 = p.Ka >> 4;
+
+  // ---- per-lane DMA sources (A: two 1 KiB pieces of the 128 x 64 B stage per wave; B: four pieces of 256 x 64 B)
+  const srd_t srdA = make_srd(p.A + ((size_t)i0 * p.lda + p.a_col0) * 4,
+                              clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda + p.Ka) * 4ull : 0ull));
+  const srd_t srdA2 = make_srd(p.A2 + ((size_t)i0 * p.lda2 + p.a2_col0) * 4,
+                               clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda2 + (p.K - p.Ka)) * 4ull : 0ull));
+  const srd_t srdW = make_srd(p.W, p.w_bytes);
+  unsigned voA[2], voA2[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 64 * q + (t >> 2);
+    const unsigned c = (unsigned)((t & 3) ^ ((row >> 2) & 3));
+    const bool in = i0 + row < p.I;
+    voA[q] = in ? (unsigned)row * (unsigned)p.lda * 4u + 16u * c : OOB;
+    voA2[q] = in ? (unsigned)row * (unsigned)p.lda2 * 4u + 16u * c : OOB;
+  }
+  const unsigned voW = 16u * (unsigned)t;
+  const unsigned w_unit0 = (unsigned)((p.w_row0 + j0) >> 5), w_ks0 = (unsigned)(p.w_k0 >> 4);
+  char* const dst0 = lds + wave * 1024;
+  auto issue = [&](int s, int slot) {
+    const bool live = s < nks, seg2 = s >= nks1;
+    const srd_t sa = seg2 ? srdA2 : srdA;
+    const unsigned so = (unsigned)(seg2 ? s - nks1 : s) * 64u;
+    char* d = dst0 + slot * KC_STAGE;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) dma16(sa, d + 4096 * q, live ? (seg2 ? voA2[q] : voA[q]) : OOB, so);
+    const unsigned sw = ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_unit0) * 2048u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dma16(srdW, d + KC_A + 4096 * q, live ? voW + 4096u * q : OOB, sw);
+  };
+  // ---- exponents along k: table in LDS + a bit per step where the scale changes (128 steps at most: K <= 2048).
+  // The loads go out first and are consumed behind the first two stage requests (their wait then counts past the DMA).
+  const int sA = lane, sB = lane + 64;
+  const int eA = sA < nks ? kc_exp_of_step(p, ti, sA, nks1) : 0;
+  const int eB = sB < nks ? kc_exp_of_step(p, ti, sB, nks1) : 0;
+  const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti, sA - 1, nks1) : eA;
+  const int eBp = sB < nks ? kc_exp_of_step(p, ti, sB - 1, nks1) : eB;
+  const int e_last = kc_exp_of_step(p, ti, nks - 1, nks1);
+  issue(0, 0);
+  issue(1, 1);
+  if (wave == 0) { etab[sA] = eA; etab[sB] = eB; }
+  const unsigned long long chg0 = __builtin_amdgcn_ballot_w64(eA != eAp), chg1 = __builtin_amdgcn_ballot_w64(eB != eBp);
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+
+  // fragment addresses: lane -> (row l & 31, k half l >> 5); chunk (2 pl + half) sits at position chunk ^ ((row >> 2) & 3)
+  const int rowl = lane & 31, kh = lane >> 5, swz = (rowl >> 2) & 3;
+  const unsigned fo0 = (unsigned)rowl * 64u + (unsigned)(((0 + kh) ^ swz) << 4);
+  const unsigned fo1 = (unsigned)rowl * 64u + (unsigned)(((2 + kh) ^ swz) << 4);
+  const unsigned fa_base = (unsigned)wi0 * 64u, fb_base = (unsigned)KC_A + (unsigned)wj0 * 64u;
+
+  auto step = [&](int s, int slot) {
+    // stage s has landed for this wave's own pieces once at most the 6 pieces of stage s + 1 are outstanding
+    wait_vm<6>();
+    barrier_raw();                       // stage s visible to all; everybody has finished reading stage s - 1
+    issue(s + 2, (slot + 2) % KC_RING);  // into the slot stage s - 1 occupied
+    if (__builtin_expect(((s < 64 ? chg0 >> s : chg1 >> (s - 64)) & 1ull) != 0ull, 0)) {
+      const int de = etab[s] - etab[s - 1];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
+    }
+    const char* st = lds + slot * KC_STAGE;
+    f16x8 bh[4], bl[4];
+#pragma unroll
+    for (int nj = 0; nj < 4; ++nj) {
+      bh[nj] = ldsfrag(st + fb_base + 2048 * nj + fo0);
+      bl[nj] = ldsfrag(st + fb_base + 2048 * nj + fo1);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      const f16x8 ah = ldsfrag(st + fa_base + 2048 * mi + fo0);
+      const f16x8 al = ldsfrag(st + fa_base + 2048 * mi + fo1);
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = mfma3(ah, al, bh[nj], bl[nj], acc[mi][nj]);
+    }
+  };
+  for (int s = 0; s < nks; s += 3) {
+    step(s, 0);
+    if (s + 1 < nks) step(s + 1, 1);
+    if (s + 2 < nks) step(s + 2, 2);
+  }
+  wait_vm<0>();        // the two dummy stages behind the last one write zeros into the ring: drain before re-using it
+  barrier_raw();
+
+  // ---- epilogue, phase A: final values of the wave's 64 x 128 tile in row layout (8 consecutive columns per lane),
+  //      their |max|, column sums; phase B (after the two waves of a 128 x 128 block have exchanged maxima): split + store.
+  const int e_in = e_last + *p.EW;          // acc = true value * 2^e_in
+  float* strip = reinterpret_cast<float*>(lds + wave * KC_STRIP);
+  const int lc = lane & 31, lh = lane >> 5;
+  const int rrow = lane >> 3, c8 = (lane & 7) * 8;
+  float val[4][4][8];
+  float wmax = 0.f;
+  int eH = 0;
+  if (AUX != AUX_NONE && j0 + wj0 < p.J) eH = p.EH[(size_t)ti * ncb_of(p.ldh) + ((p.h_col0 + j0 + wj0) >> 7)];
+  const float inv_h = pow2f(-eH);
+  const size_t offH = uniform_sz(((size_t)(i0 + wi0) * p.ldh + p.h_col0) * 4);
+  const srd_t srdH = make_srd(AUX != AUX_NONE ? p.H + offH : nullptr, AUX != AUX_NONE ? 0xFFFFFFE0u : 0u);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int mi = b >> 1, hj = b & 1;
+    const int rbase = i0 + wi0 + 32 * mi, col = j0 + wj0 + 64 * hj + c8;
+    const bool col_ok = col < p.J;
+    u32x4 hh[AUX != AUX_NONE ? 4 : 1], hl[AUX != AUX_NONE ? 4 : 1];
+    unsigned sword = 0u;
+    if (AUX != AUX_NONE) {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const int rl = 32 * mi + rrow + 8 * ps;
+        const bool ok = col_ok && (i0 + wi0 + rl) < p.I;
+        const unsigned o = ok ? (unsigned)rl * (unsigned)p.ldh * 4u + (unsigned)(col >> 4) * 64u + (unsigned)(col & 8) * 2u : OOB;
+        hh[ps] = __builtin_amdgcn_raw_buffer_load_b128(srdH, o, 0, 0);
+        hl[ps] = __builtin_amdgcn_raw_buffer_load_b128(srdH, o == OOB ? OOB : o + 32u, 0, 0);
+      }
+      if (AUX == AUX_SINREC) {
+        const size_t sidx = ((size_t)(rbase >> 5) * ((p.ldh + 63) >> 6) + ((p.h_col0 + col - c8) >> 6)) * 64 + lane;
+        sword = p.Hsign[(col_ok && rbase < p.I) ? sidx : 0];
+      }
+    }
+    float bj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr && col_ok) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+      bj[0] = b0.x; bj[1] = b0.y; bj[2] = b0.z; bj[3] = b0.w; bj[4] = b1.x; bj[5] = b1.y; bj[6] = b1.z; bj[7] = b1.w;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + 32 * n + lc] = __builtin_amdgcn_ldexpf(acc[mi][2 * hj + n][r], -e_in);
+    unsigned sbits = 0u;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const bool ok = col_ok && (rbase + rrow + 8 * ps) < p.I;
+      const float4 x0 = *reinterpret_cast<const float4*>(&strip[(rrow + 8 * ps) * 68 + c8]);
+      const float4 x1 = *reinterpret_cast<const float4*>(&strip[(rrow + 8 * ps) * 68 + c8 + 4]);
+      float v[8] = {x0.x + bj[0], x0.y + bj[1], x0.z + bj[2], x0.w + bj[3], x1.x + bj[4], x1.y + bj[5], x1.z + bj[6], x1.w + bj[7]};
+      if (ACT == ACT_SIN) {
+        unsigned n0, n1;
+        const float4 s0 = sin4_signcos(make_float4(p.w0 * v[0], p.w0 * v[1], p.w0 * v[2], p.w0 * v[3]), &n0);
+        const float4 s1 = sin4_signcos(make_float4(p.w0 * v[4], p.w0 * v[5], p.w0 * v[6], p.w0 * v[7]), &n1);
+        v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
+        sbits |= (n0 | (n1 << 4)) << (8 * ps);
+      } else if (ACT == ACT_RELU) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
+      }
+      if (AUX != AUX_NONE) {
+        float h[8];
+        join8(hh[ps], hl[ps], inv_h, h);
+        if (AUX == AUX_SINREC) {
+          const unsigned byte = sword >> (8 * ps);
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            const float d = p.w0 * cos_from_sin(h[c]);
+            v[c] *= ((byte >> c) & 1u) ? -d : d;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) v[c] = h[c] > 0.f ? v[c] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        v[c] = ok ? v[c] : 0.f;
+        wmax = fmaxf(wmax, fabsf(v[c]));
+        if (COLSUM) cs[c] += v[c];
+        val[b][ps][c] = v[c];
+      }
+    }
+    if (ACT == ACT_SIN && p.Csign != nullptr && col_ok && rbase < p.I)
+      p.Csign[((size_t)(rbase >> 5) * ((p.ldc + 63) >> 6) + ((p.c_col0 + col - c8) >> 6)) * 64 + lane] = sbits;
+    if (COLSUM && p.colsum != nullptr) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) cs[c] += __shfl_xor(cs[c], o, 64);
+      if (lane < 8 && col_ok && rbase < p.I) {
+        float* d = p.colsum + (size_t)(rbase >> 5) * p.ldcs + col;
+        *reinterpret_cast<float4*>(d) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        *reinterpret_cast<float4*>(d + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+      }
+    }
+  }
+  // block maximum: the waves (0, wc) and (1, wc) share the exponent block (ti, column block of wc)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
+  if (lane == 0) smax[wave] = wmax;
+  __syncthreads();
+  const float bmax = fmaxf(smax[wc], smax[2 + wc]);
+  const int eC = exp_of_maxbits(__float_as_uint(bmax));
+  const float sc = pow2f(eC);
+  if (wr == 0 && lane == 0 && j0 + wj0 < p.J) p.EC[(size_t)ti * ncb_of(p.ldc) + ((p.c_col0 + j0 + wj0) >> 7)] = eC;
+  const size_t offC = uniform_sz(((size_t)(i0 + wi0) * p.ldc + p.c_col0) * 4);
+  const srd_t srdC = make_srd(p.C + offC, 0xFFFFFFE0u);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int mi = b >> 1, hj = b & 1;
+    const int col = j0 + wj0 + 64 * hj + c8;
+    const bool col_ok = col < p.J;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int rl = 32 * mi + rrow + 8 * ps;
+      const bool ok = col_ok && (i0 + wi0 + rl) < p.I;
+      u32x4 hi, lo;
+      split8(val[b][ps], sc, hi, lo);
+      const unsigned o = ok ? (unsigned)rl * (unsigned)p.ldc * 4u + (unsigned)(col >> 4) * 64u + (unsigned)(col & 8) * 2u : OOB;
+      __builtin_amdgcn_raw_buffer_store_b128(hi, srdC, o, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(lo, srdC, o == OOB ? OOB : o + 32u, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// K-contiguous GEMM, 32-wide fp32 output (pre-activations of sigma / sun visibility / final head layers: the composite
+// kernels apply their activations).  128 x 32 tile, four waves of 32 x 32.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int KN_A = 128 * 64, KN_B = 32 * 64, KN_STAGE = KN_A + KN_B, KN_TAIL = 3 * KN_STAGE, KN_DUMMY = KN_TAIL + 512, KN_LDS = KN_DUMMY + 2048;
+
+__global__ __launch_bounds__(256, 4) void gemm_kcn_kernel(const KcArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[KN_LDS];
+  int* etab = reinterpret_cast<int*>(lds + KN_TAIL);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int ti = blockIdx.x, i0 = ti * 128, wi0 = wave * 32;
+  const int nks = p.K >> 4, nks1 = p.Ka >> 4;
+  const srd_t srdA = make_srd(p.A + ((size_t)i0 * p.lda + p.a_col0) * 4,
+                              clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda + p.Ka) * 4ull : 0ull));
+  const srd_t srdW = make_srd(p.W, p.w_bytes);
+  unsigned voA[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int row = 64 * q + (t >> 2);
+    const unsigned c = (unsigned)((t & 3) ^ ((row >> 2) & 3));
+    voA[q] = (i0 + row < p.I) ? (unsigned)row * (unsigned)p.lda * 4u + 16u * c : OOB;
+  }
+  // the 2 KiB weight stage is two pieces: waves 0 and 1 fetch one each; waves 2 and 3 issue a rejected (zero-traffic)
+  // piece into a scratch KiB of their own so that every wave counts three pieces per stage
+  const unsigned voW = wave < 2 ? 16u * (unsigned)t : OOB;
+  const unsigned w_unit0 = (unsigned)(p.w_row0 >> 5), w_ks0 = (unsigned)(p.w_k0 >> 4);
+  auto issue = [&](int s, int slot) {
+    const bool live = s < nks;
+    char* d = lds + slot * KN_STAGE;
+    const unsigned sw = ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_unit0) * 2048u;
+    dma16(srdW, wave < 2 ? d + KN_A + wave * 1024 : lds + KN_DUMMY + (wave - 2) * 1024, live ? voW : OOB, sw);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) dma16(srdA, d + 4096 * q + wave * 1024, live ? voA[q] : OOB, (unsigned)s * 64u);
+  };
+  const int sA = lane, sB = lane + 64;
+  const int eA = sA < nks ? kc_exp_of_step(p, ti, sA, nks1) : 0;
+  const int eB = sB < nks ? kc_exp_of_step(p, ti, sB, nks1) : 0;
+  const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti, sA - 1, nks1) : eA;
+  const int eBp = sB < nks ? kc_exp_of_step(p, ti, sB - 1, nks1) : eB;
+  const int e_last = kc_exp_of_step(p, ti, nks - 1, nks1);
+  issue(0, 0);
+  issue(1, 1);
+  if (wave == 0) { etab[sA] = eA; etab[sB] = eB; }
+  const unsigned long long chg0 = __builtin_amdgcn_ballot_w64(eA != eAp), chg1 = __builtin_amdgcn_ballot_w64(eB != eBp);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int rowl = lane & 31, kh = lane >> 5, swz = (rowl >> 2) & 3;
+  const unsigned fo0 = (unsigned)rowl * 64u + (unsigned)(((0 + kh) ^ swz) << 4);
+  const unsigned fo1 = (unsigned)rowl * 64u + (unsigned)(((2 + kh) ^ swz) << 4);
+  auto step = [&](int s, int slot) {
+    wait_vm<3>();
+    barrier_raw();
+    issue(s + 2, (slot + 2) % 3);
+    if (__builtin_expect(((s < 64 ? chg0 >> s : chg1 >> (s - 64)) & 1ull) != 0ull, 0)) acc = scale_acc(acc, etab[s] - etab[s - 1]);
+    const char* st = lds + slot * KN_STAGE;
+    acc = mfma3(ldsfrag(st + wi0 * 64 + fo0), ldsfrag(st + wi0 * 64 + fo1), ldsfrag(st + KN_A + fo0), ldsfrag(st + KN_A + fo1), acc);
+  };
+  for (int s = 0; s < nks; s += 3) {
+    step(s, 0);
+    if (s + 1 < nks) step(s + 1, 1);
+    if (s + 2 < nks) step(s + 2, 2);
+  }
+  wait_vm<0>();
+  const int e_in = e_last + *p.EW;
+  const int col = lane & 31;
+  const float bj = (p.bias != nullptr && col < p.J) ? p.bias[col] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = i0 + wi0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < p.I && col < p.J) p.Cf[(size_t)row * 32 + col] = __builtin_amdgcn_ldexpf(acc[r], -e_in) + bj;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dW = dZ^T X: both operands point-contiguous BSP, transposed fragment reads, split-K slabs in fp32
+// ------------------------------------------------------------------------------------------------------------------
+// TI = 256: 512 threads, eight waves of 128 x 64 (2 x 4), one workgroup per CU.  TI = 32: 256 threads, four waves of 32 x 64.
+template <int TI> struct DwCfg {
+  static constexpr int NTH = TI == 256 ? 512 : 256, WAVES = NTH / 64;
+  static constexpr int MI = TI == 256 ? 4 : 1;                   // 32-row blocks per wave along i
+  static constexpr int A_PITCH = TI * 4;                         // bytes of one point row of the A stage (TI columns, both planes)
+  static constexpr int A_BYTES = 16 * A_PITCH, B_BYTES = 16 * 1024, STAGE = A_BYTES + B_BYTES, RING = 3;
+  static constexpr int STRIPS = WAVES * KC_STRIP;
+  static constexpr int TAIL = (RING * STAGE > STRIPS) ? RING * STAGE : STRIPS;
+  static constexpr int MAXCH = 128;                              // 128-point chunks per split (k_split <= 16384)
+  static constexpr int DUMMY = TAIL + WAVES * MAXCH * 4;        // scratch KiB per wave for rejected pieces (the narrow form)
+  static constexpr int LDS = DUMMY + (TI == 256 ? 0 : WAVES * 1024);
+};
+// byte swizzle of point row p inside a stage: 1 KiB rows put the four rows of a transposed-read block into four bank
+// quarters; the 128-byte rows of the 32-column form need only the hi/lo flip of the upper two rows
+template <int PITCH> __device__ __forceinline__ unsigned dw_swz(int p) {
+  return PITCH == 1024 ? (unsigned)(((p & 1) << 5) | ((p & 2) << 6)) : (unsigned)((p & 2) << 4);
+}
+
+template <int TI>
+__global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_kernel(const DwArgs p) {
+  using T = DwCfg<TI>;
+  __shared__ __attribute__((aligned(16))) char lds[T::LDS];
+  int* esum = reinterpret_cast<int*>(lds + T::TAIL);       // [wave][chunk]: exponent of dZ block + exponent of X block
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wi0 = TI == 256 ? (wave >> 2) * 128 : 0, wj0 = (wave & 3) * 64;
+  int tile, split;
+  split_tile_of_block(blockIdx.x, blockIdx.z, gridDim.x, gridDim.z, tile, split);
+  const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
+  const int i0 = ti * TI, j0 = tj * 256;
+  const int kBeg = split * p.k_split, kEnd = min(p.P, kBeg + p.k_split);
+  const int nks = (kEnd - kBeg + 15) >> 4;
+  float* C = p.C + (size_t)split * p.slab_stride;
+
+  // ---- DMA sources: a piece is 1 KiB = one point row of the 256-column operand (eight 128-byte rows of the 32-column one)
+  const srd_t srdA = make_srd(p.A + ((size_t)kBeg * p.lda + p.a_col0 + i0) * 4,
+                              clamp_bytes(kEnd > kBeg ? ((unsigned long long)(kEnd - kBeg) * p.lda - (p.a_col0 + i0)) * 4ull : 0ull));
+  const srd_t srdB = make_srd(p.B + ((size_t)kBeg * p.ldb + p.b_col0 + j0) * 4,
+                              clamp_bytes(kEnd > kBeg ? ((unsigned long long)(kEnd - kBeg) * p.ldb - (p.b_col0 + j0)) * 4ull : 0ull));
+  constexpr int PA = T::A_PITCH;
+  constexpr int A_PIECES = T::A_BYTES / 1024;                         // 16 (TI = 256) or 2 (TI = 32)
+  constexpr int NPA = (A_PIECES + T::WAVES - 1) / T::WAVES;           // A pieces per wave: 2 / 1 (waves >= 2 of the narrow form: a rejected one)
+  constexpr int NPB = 16 / T::WAVES;                                  // B pieces per wave: 2 / 4
+  unsigned voA[NPA], voB[NPB];
+  int prA[NPA], prB[NPB];        // point row (inside the stage) each piece's lane belongs to
+#pragma unroll
+  for (int q = 0; q < NPA; ++q) {
+    const int piece = wave * NPA + q;
+    const int pr = PA == 1024 ? piece : piece * 8 + (lane >> 3);
+    const unsigned byte = PA == 1024 ? 16u * lane : 16u * (lane & 7);
+    prA[q] = piece < A_PIECES ? pr : -1;
+    voA[q] = (unsigned)pr * (unsigned)p.lda * 4u + (byte ^ dw_swz<PA>(pr));
+  }
+#pragma unroll
+  for (int q = 0; q < NPB; ++q) {
+    const int pr = wave * NPB + q;
+    prB[q] = pr;
+    voB[q] = (unsigned)pr * (unsigned)p.ldb * 4u + ((16u * lane) ^ dw_swz<1024>(pr));
+  }
+  auto issue = [&](int s, int slot) {
+    const int prow0 = kBeg + 16 * s;
+    char* d = lds + slot * T::STAGE;
+#pragma unroll
+    for (int q = 0; q < NPA; ++q) {
+      const int piece = wave * NPA + q;
+      const bool ok = s < nks && prA[q] >= 0 && prow0 + prA[q] < kEnd;
+      dma16(srdA, piece < A_PIECES ? d + piece * 1024 : lds + T::DUMMY + wave * 1024, ok ? voA[q] : OOB, (unsigned)s * 16u * (unsigned)p.lda * 4u);
+    }
+#pragma unroll
+    for (int q = 0; q < NPB; ++q) {
+      const bool ok = s < nks && prow0 + prB[q] < kEnd;
+      dma16(srdB, d + T::A_BYTES + prB[q] * 1024, ok ? voB[q] : OOB, (unsigned)s * 16u * (unsigned)p.ldb * 4u);
+    }
+  };
+  // ---- exponent sums per 128-point chunk, per wave (its 128-row / 64-column sub-tile lies in one block of either tensor)
+  const int nch = (kEnd - kBeg + 127) >> 7;
+  {
+    const int ncbA = ncb_of(p.lda), ncbB = ncb_of(p.ldb);
+    // sub-tiles entirely beyond I / J (their results are never stored) clamp to the last block of the table row
+    const int cbA = min((p.a_col0 + i0 + wi0) >> 7, ncbA - 1), cbB = min((p.b_col0 + j0 + wj0) >> 7, ncbB - 1);
+    for (int c = lane; c < nch; c += 64) {
+      const size_t rb = (size_t)(kBeg >> 7) + c;
+      esum[wave * T::MAXCH + c] = p.EA[rb * ncbA + cbA] + p.EB[rb * ncbB + cbB];
+    }
+  }
+
+  issue(0, 0);
+  issue(1, 1);
+
+  f32x16 acc[T::MI][2];
+#pragma unroll
+  for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+
+  // transposed fragment reads: 16-lane group g: columns 16 (g & 1) ..+15 of a 32-column block, points 8 (g >> 1) + {0, 4} + q;
+  // lane 4 q + pp of the group addresses point row q, columns 4 pp .. 4 pp + 3 (8 bytes)
+  const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
+  const int kq = 8 * (g >> 1) + q4;
+  auto frag_off = [&](int col, int pl, int pitch, unsigned sw) -> unsigned {   // col: first column of the 16-group (% 16 == 0)
+    return (unsigned)kq * (unsigned)pitch + ((((unsigned)(col >> 4) * 64u) + (unsigned)pl * 32u + 8u * (unsigned)pp) ^ sw);
+  };
+  unsigned foA[T::MI][2], foB[2][2];
+#pragma unroll
+  for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) foA[mi][pl] = frag_off(wi0 + 32 * mi + 16 * (g & 1), pl, PA, dw_swz<PA>(q4));
+#pragma unroll
+  for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) foB[nj][pl] = (unsigned)T::A_BYTES + frag_off(wj0 + 32 * nj + 16 * (g & 1), pl, 1024, dw_swz<1024>(q4));
+  typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+  typedef h4_t __attribute__((address_space(3))) * lds4_t;
+  auto trfrag = [&](const char* base, unsigned off, int pitch) -> f16x8 {
+    const f16x4 a = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4_t)(base + off)));
+    const f16x4 b = __builtin_bit_cast(f16x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds4_t)(base + off + 4 * pitch)));
+    return f16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  };
+
+  int e_cur = 0;
+  constexpr int NPIECE = NPA + NPB;
+  auto step = [&](int s, int slot) {
+    wait_vm<NPIECE>();
+    barrier_raw();
+    issue(s + 2, (slot + 2) % 3);
+    if ((s & 7) == 0) {     // a new 128-point chunk: its own pair of exponents
+      const int e_new = __builtin_amdgcn_readfirstlane(esum[wave * T::MAXCH + (s >> 3)]);
+      if (s == 0) e_cur = e_new;
+      else if (__builtin_expect(e_new != e_cur, 0)) {
+        const int de = e_new - e_cur;
+#pragma unroll
+        for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
+        e_cur = e_new;
+      }
+    }
+    const char* st = lds + slot * T::STAGE;
+    f16x8 bh[2], bl[2];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) { bh[nj] = trfrag(st, foB[nj][0], 1024); bl[nj] = trfrag(st, foB[nj][1], 1024); }
+#pragma unroll
+    for (int mi = 0; mi < T::MI; ++mi) {
+      const f16x8 ah = trfrag(st, foA[mi][0], PA), al = trfrag(st, foA[mi][1], PA);
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = mfma3(ah, al, bh[nj], bl[nj], acc[mi][nj]);
+    }
+  };
+  for (int s = 0; s < nks; s += 3) {
+    step(s, 0);
+    if (s + 1 < nks) step(s + 1, 1);
+    if (s + 2 < nks) step(s + 2, 2);
+  }
+  wait_vm<0>();
+  barrier_raw();
+
+  // ---- epilogue: fp32 slab rows through the wave's LDS strip (16-byte stores, 256 contiguous bytes per row)
+  float* strip = reinterpret_cast<float*>(lds + wave * KC_STRIP);
+  const int lc = lane & 31, lh = lane >> 5;
+  const int rrow = lane >> 4, c4 = (lane & 15) * 4;
+  const int col = j0 + wj0 + c4;
+  const size_t offC = uniform_sz((size_t)(i0 + wi0) * p.ldc + j0 + wj0);
+  const srd_t srdC = make_srd(C + offC, 0xFFFFFFE0u);
+#pragma unroll
+  for (int mi = 0; mi < T::MI; ++mi) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + 32 * n + lc] = __builtin_amdgcn_ldexpf(acc[mi][n][r], -e_cur);
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int rl = 32 * mi + rrow + 4 * ps;
+      const bool ok = col < p.J && (i0 + wi0 + rl) < p.I;    // J % 4 == 0
+      const float4 v = *reinterpret_cast<const float4*>(&strip[(rrow + 4 * ps) * 68 + c4]);
+      const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+      __builtin_amdgcn_raw_buffer_store_b128(d, srdC, ok ? ((unsigned)rl * (unsigned)p.ldc + (unsigned)c4) * 4u : OOB, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+int prof_hook_begin(double flops, int variant, hipStream_t st);   // gemm.hip: per-launch HIP events when profiling is on
+void prof_hook_end(int token, hipStream_t st);
+
+static int bad(const char* why) {
+  set_error("bsp gemm: %s", why);
+  return SNERF_ERR_BAD_DESC;
+}
+
+static int check_kc(const KcArgs& a, bool narrow) {
+  if (!a.A || !a.EA || !a.W || !a.EW) return bad("null operand");
+  if (a.I <= 0 || a.J <= 0 || a.K <= 0) return bad("empty problem");
+  if ((a.K & 15) || (a.Ka & 15) || a.Ka <= 0 || a.Ka > a.K || a.K > 2048) return bad("K and Ka must be multiples of 16, K <= 2048");
+  if ((a.lda & 15) || (a.a_col0 & 15) || a.a_col0 + a.Ka > a.lda) return bad("A segment does not fit its tensor (16-column groups)");
+  if (a.Ka < a.K && (!a.A2 || !a.EA2 || (a.lda2 & 15) || (a.a2_col0 & 15) || a.a2_col0 + (a.K - a.Ka) > a.lda2)) return bad("second A segment");
+  if ((a.w_row0 & 31) || (a.w_k0 & 15) || a.w_rb32 <= 0) return bad("weight operand must start on a 32-row / 16-k unit");
+  if ((size_t)128 * (a.lda > a.lda2 ? a.lda : a.lda2) * 4 >= 0x7FFFFFFFull) return bad("leading dimension too large");
+  if (((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || (a.A2 && ((uintptr_t)a.A2 & 15))) return bad("operands must be 16-byte aligned");
+  if (narrow) {
+    if (!a.Cf || a.J > 32 || a.Ka != a.K) return bad("narrow variant: fp32 output, J <= 32, one A segment");
+    return SNERF_OK;
+  }
+  if (!a.C || !a.EC || (a.ldc & 15) || (a.c_col0 & 127) || (a.J & 15) || a.c_col0 + a.J > a.ldc) return bad("BSP output: ldc % 16, c_col0 % 128, J % 16");
+  if (((uintptr_t)a.C & 15) || (a.bias && ((uintptr_t)a.bias & 15))) return bad("output / bias alignment");
+  if (a.aux_mode != AUX_NONE) {
+    if (a.aux_mode != AUX_SINREC && a.aux_mode != AUX_RELU_MASK) return bad("unsupported aux mode");
+    if (!a.H || !a.EH || (a.ldh & 15) || (a.h_col0 & 127) || a.h_col0 + a.J > a.ldh) return bad("aux tensor: ldh % 16, h_col0 % 128");
+    if (a.aux_mode == AUX_SINREC && !a.Hsign) return bad("AUX_SINREC needs the sign words");
+    if (a.act != ACT_NONE) return bad("activation and derivative in one epilogue");
+  }
+  if (a.colsum && (((uintptr_t)a.colsum & 15) || (a.ldcs & 3))) return bad("colsum alignment");
+  if ((size_t)128 * a.ldc * 4 >= 0x7FFFFFFFull) return bad("ldc too large");
+  return SNERF_OK;
+}
+
+int launch_kc(const KcArgs& a0, hipStream_t st) {
+  KcArgs a = a0;
+  if (!a.A2) { a.A2 = a.A; a.EA2 = a.EA; a.lda2 = a.lda; a.a2_col0 = a.a_col0; if (a.Ka == 0) a.Ka = a.K; }
+  int rc = check_kc(a, false);
+  if (rc) return rc;
+  a.tiles_i = (a.I + 127) / 128;
+  a.tiles_j = (a.J + 255) / 256;
+  const dim3 grid(a.tiles_i * a.tiles_j), block(256);
+  const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.K, 0, st);
+  const bool cs = a.colsum != nullptr;
+#define KC_LAUNCH(ACT_, AUX_, CS_) hipLaunchKernelGGL((gemm_kc_kernel<ACT_, AUX_, CS_>), grid, block, 0, st, a)
+  if (a.aux_mode == AUX_SINREC) KC_LAUNCH(ACT_NONE, AUX_SINREC, true);
+  else if (a.aux_mode == AUX_RELU_MASK) KC_LAUNCH(ACT_NONE, AUX_RELU_MASK, true);
+  else if (a.act == ACT_SIN) KC_LAUNCH(ACT_SIN, AUX_NONE, false);
+  else if (a.act == ACT_RELU) KC_LAUNCH(ACT_RELU, AUX_NONE, false);
+  else if (cs) KC_LAUNCH(ACT_NONE, AUX_NONE, true);
+  else KC_LAUNCH(ACT_NONE, AUX_NONE, false);
+#undef KC_LAUNCH
+  SNERF_LAUNCH_CHECK();
+  prof_hook_end(tok, st);
+  return SNERF_OK;
+}
+
+int launch_kc_narrow(const KcArgs& a0, hipStream_t st) {
+  KcArgs a = a0;
+  if (a.Ka == 0) a.Ka = a.K;
+  a.A2 = a.A; a.EA2 = a.EA; a.lda2 = a.lda; a.a2_col0 = a.a_col0;
+  int rc = check_kc(a, true);
+  if (rc) return rc;
+  const int tok = prof_hook_begin(2.0 * a.I * 32.0 * a.K, 3, st);
+  hipLaunchKernelGGL(gemm_kcn_kernel, dim3((a.I + 127) / 128), dim3(256), 0, st, a);
+  SNERF_LAUNCH_CHECK();
+  prof_hook_end(tok, st);
+  return SNERF_OK;
+}
+
+int launch_dw(const DwArgs& a0, bool narrow_i, hipStream_t st) {
+  DwArgs a = a0;
+  if (!a.A || !a.EA || !a.B || !a.EB || !a.C) return bad("dW: null operand");
+  if (a.I <= 0 || a.J <= 0 || a.P <= 0) return bad("dW: empty problem");
+  if ((a.lda & 15) || (a.ldb & 15) || (a.a_col0 & 15) || (a.b_col0 & 15) || (a.J & 3) || (a.ldc & 3)) return bad("dW: leading dimensions / column offsets");
+  if (a.k_split <= 0 || (a.k_split & 127) || a.k_split > 16384 || a.n_split < 1) return bad("dW: k_split must be a multiple of 128, <= 16384");
+  if ((size_t)a.k_split * (a.lda > a.ldb ? a.lda : a.ldb) * 4 >= 0xFFFFFFF0ull) return bad("dW: k_split * ld exceeds the 32-bit span");
+  if (narrow_i ? (a.I > 32 || ((a.a_col0 & 127) + 32 > 128)) : ((a.a_col0 & 127) != 0)) return bad("dW: the A columns of a wave must lie in one exponent block");
+  if (a.b_col0 & 63) return bad("dW: b_col0 % 64");
+  if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15)) return bad("dW: alignment");
+  const int TI = narrow_i ? 32 : 256;
+  a.tiles_i = (a.I + TI - 1) / TI;
+  a.tiles_j = (a.J + 255) / 256;
+  const dim3 grid(a.tiles_i * a.tiles_j, 1, a.n_split);
+  const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.P, narrow_i ? 3 : 2, st);
+  if (narrow_i) hipLaunchKernelGGL(gemm_dw_kernel<32>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(gemm_dw_kernel<256>, grid, dim3(512), 0, st, a);
+  SNERF_LAUNCH_CHECK();
+  prof_hook_end(tok, st);
+  return SNERF_OK;
+}
+
+}  // namespace bsp
+}  // namespace snerf

@@ -292,6 +292,21 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
   return SNERF_OK;
 }
 
+// the same per-launch bracket for the launchers of bsp_gemm.hip
+namespace bsp {
+int prof_hook_begin(double flops, int variant, hipStream_t st) {
+  if (!g_prof_on) return -1;
+  ProfRec rec{prof_event(), prof_event(), flops, variant};
+  if (!rec.a || !rec.b) return -1;
+  (void)hipEventRecord(rec.a, st);
+  g_prof.push_back(rec);
+  return (int)g_prof.size() - 1;
+}
+void prof_hook_end(int token, hipStream_t st) {
+  if (token >= 0) (void)hipEventRecord(g_prof[token].b, st);
+}
+}  // namespace bsp
+
 int profile_begin() {
   g_prof.clear();
   g_prof_used = 0;

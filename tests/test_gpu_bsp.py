@@ -1,0 +1,220 @@
+"""Kernel-level GPU tests of the block-scaled fp16-plane path (csrc/bsp.h): storage round trip, the K-contiguous GEMM
+with every epilogue the passes use, the 32-wide variant, and the weight-gradient GEMM -- each against an fp64 reference
+of the same operation, through the C-ABI test hooks.
+
+Accuracy bar: the three-product fp16 contraction of 22-bit operands is fp32-class -- normwise error below that of a plain
+fp32 GEMM of the same shape -- and, because every 128 x 128 block carries its own exponent, ROW-wise too: a quiet row
+block next to a loud one keeps its own precision (the heavy-tail cases)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ACT_NONE, ACT_SIN, ACT_RELU = 0, 1, 2
+AUX_NONE, AUX_RELU_MASK, AUX_SINREC = 0, 2, 3
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _lib():
+    from snerf_amd import _lib
+    return _lib.lib(), _lib
+
+
+def _relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-300))
+
+
+def test_planes_round_trip_and_block_exponents():
+    L, lib = _lib()
+    g = torch.Generator().manual_seed(0)
+    rows, cols = 300, 200
+    x = torch.randn(rows, cols, generator=g)
+    x[:128] *= 1e-6           # a quiet row block
+    x[128:256, :128] *= 3e3   # a loud block
+    x = x.to(DEV)
+    ld, col0 = 384, 128
+    y = torch.empty_like(x)
+    E = torch.zeros(3 * 3, dtype=torch.int32, device=DEV)
+    lib.check(L.snerf_test_bsp_roundtrip(_p(x), rows, cols, ld, col0, _p(y), _p(E), _st()), "roundtrip")
+    # 22 significant bits relative to each BLOCK's maximum
+    for rb in range(3):
+        for cb in range(2):
+            blk = (slice(128 * rb, min(rows, 128 * rb + 128)), slice(128 * cb, min(cols, 128 * cb + 128)))
+            m = float(x[blk].abs().max())
+            assert float((y[blk] - x[blk]).abs().max()) <= m * 2.0 ** -21, (rb, cb)
+            e = int(E[rb * 3 + 1 + cb])
+            assert 2.0 ** 13 <= m * 2.0 ** e < 2.0 ** 14, (rb, cb, e, m)
+
+
+def _kc(A, W, bias=None, A2=None, act=ACT_NONE, w0=1.0, aux=AUX_NONE, Hact=None, Hsign=None, a_col0=0, c_col0=0,
+        want_sign=False, want_colsum=False, narrow=False):
+    L, lib = _lib()
+    I, Ka = A.shape
+    K = Ka + (A2.shape[1] if A2 is not None else 0)
+    J = W.shape[0]
+    Cm = torch.full((I, 32 if narrow else J), float("nan"), device=DEV)
+    ldc = c_col0 + (J + 15) // 16 * 16
+    sign = torch.zeros(((I + 127) // 128 * 128 // 32) * ((ldc + 63) // 64) * 64, dtype=torch.int32, device=DEV) if want_sign else None
+    cs = torch.zeros(((I + 31) // 32, J), device=DEV) if want_colsum else None
+    lib.check(L.snerf_test_bsp_kc(_p(A), _p(A2), Ka, _p(W), _p(bias), I, J, K, a_col0, c_col0, act, w0, aux, _p(Hact), _p(Hsign),
+                                  _p(Cm), _p(sign), _p(cs), int(narrow), _st()), "test_bsp_kc")
+    return Cm, sign, cs
+
+
+@pytest.mark.parametrize("I,J,K", [(128, 256, 16), (300, 512, 512), (1000, 544, 528), (257, 48, 64), (4096, 1024, 544)])
+def test_kc_plain_and_bias(I, J, K):
+    g = torch.Generator().manual_seed(I + J + K)
+    A = torch.randn(I, K, generator=g).to(DEV)
+    W = (torch.randn(J, K, generator=g) * 0.05).to(DEV)
+    b = torch.randn(J, generator=g).to(DEV)
+    Cm, _, cs = _kc(A, W, b, want_colsum=True)
+    ref = A.double() @ W.double().T + b.double()
+    fp32 = A @ W.T + b
+    err, err32 = _relerr(Cm, ref), _relerr(fp32, ref)
+    assert err <= max(2.0 * err32, 2e-7), (err, err32)
+    # bias-gradient partials: per 32-row block column sums of the stored values
+    want = torch.stack([ref[r:r + 32].sum(0) for r in range(0, I, 32)])
+    assert _relerr(cs, want) <= 1e-5
+
+
+def test_kc_two_segments_offsets_and_exponent_changes():
+    """[gamma | h] style two-segment A, A placed at a column offset, output at a column offset, and A blocks whose
+    magnitudes differ by 2^20 along k: the accumulators are rescaled between column blocks (and segments)"""
+    g = torch.Generator().manual_seed(7)
+    I, Ka, Kb, J = 384, 256, 272, 512
+    A = torch.randn(I, Ka, generator=g)
+    A[:, 128:] *= 2.0 ** -20
+    A[128:256] *= 2.0 ** 9
+    A2 = torch.randn(I, Kb, generator=g) * 37.0
+    W = torch.randn(J, Ka + Kb, generator=g)
+    A, A2, W = A.to(DEV), A2.to(DEV), W.to(DEV)
+
+    def check(Am, A2m, Wm, **kw):
+        Cm, _, _ = _kc(Am, Wm, None, A2=A2m, **kw)
+        cat = Am if A2m is None else torch.cat([Am, A2m], 1)
+        ref = cat.double() @ Wm.double().T
+        rows = (Cm.double() - ref).norm(dim=1) / ref.norm(dim=1)
+        rows32 = ((cat @ Wm.T).double() - ref).norm(dim=1) / ref.norm(dim=1)
+        assert float(rows.max()) <= max(4.0 * float(rows32.max()), 4e-7), (float(rows.max()), float(rows32.max()))
+    check(A, A2, W, a_col0=128, c_col0=256)            # loud, quiet (2^-20), loud segment: two rescales up / down
+    check(A, None, W[:, :Ka].contiguous(), a_col0=128)  # ends on the quiet block
+    # the quiet block alone decides the result when the loud columns meet zero weights: it must keep its own 22 bits
+    Wz = W.clone()
+    Wz[:, :128] = 0
+    Wz[:, Ka:] = 0
+    check(A, A2, Wz, a_col0=128, c_col0=128)
+
+
+@pytest.mark.parametrize("I,J,K,w0", [(300, 512, 64, 30.0), (1000, 1024, 544, 1.0)])
+def test_kc_siren_forward_then_derivative_epilogue(I, J, K, w0):
+    """forward: h = sin(w0 (x W^T + b)) + sign words of cos; backward epilogue: (g W2^T) * w0 cos(w0 z) rebuilt from the
+    stored h and the sign bits, + column sums"""
+    g = torch.Generator().manual_seed(I + K)
+    X = (torch.rand(I, K, generator=g) * 2 - 1).to(DEV)
+    W = (torch.randn(J, K, generator=g) * (0.3 / K ** 0.5)).to(DEV)
+    b = (torch.randn(J, generator=g) * 0.1).to(DEV)
+    H, sign, _ = _kc(X, W, b, act=ACT_SIN, w0=w0, want_sign=True, c_col0=128)
+    z = (X.double() @ W.double().T + b.double()) * w0
+    assert float((H.double() - torch.sin(z)).abs().max()) <= 4e-6 * max(1.0, w0 / 8)
+    Kg = 256
+    G = torch.randn(I, Kg, generator=g).to(DEV)
+    G[:128] *= 1e-7                                     # a quiet block of gradient rows
+    W2 = (torch.randn(J, Kg, generator=g) * 0.05).to(DEV)
+    D, _, cs = _kc(G, W2, None, aux=AUX_SINREC, Hact=H, Hsign=sign, w0=w0, want_colsum=True, c_col0=128)
+    ref = (G.double() @ W2.double().T) * (w0 * torch.cos(z))
+    # where |cos| is tiny the rebuilt sqrt(1 - h^2) carries h's rounding: compare normwise per row
+    rows = (D.double() - ref).norm(dim=1) / ref.norm(dim=1)
+    tol = 2e-5 * max(1.0, w0 / 6)   # |cos| = sqrt(1 - h^2) amplifies h's rounding by w0 |tan|: measured 4e-5 at w0 = 30, 1e-5 at 1
+    assert float(rows.max()) <= tol, float(rows.max())
+    assert float(rows[:128].max()) <= tol                 # the quiet rows are as accurate as the loud ones
+    want = torch.stack([ref[r:r + 32].sum(0) for r in range(0, I, 32)])
+    assert _relerr(cs, want) <= 1e-4
+
+
+def test_kc_relu_forward_and_mask():
+    g = torch.Generator().manual_seed(11)
+    I, J, K = 520, 256, 96
+    X = torch.randn(I, K, generator=g).to(DEV)
+    W = torch.randn(J, K, generator=g).to(DEV)
+    H, _, _ = _kc(X, W, None, act=ACT_RELU)
+    ref = torch.relu(X.double() @ W.double().T)
+    assert _relerr(H, ref) <= 3e-7
+    G = torch.randn(I, 64, generator=g).to(DEV)
+    W2 = torch.randn(J, 64, generator=g).to(DEV)
+    D, _, _ = _kc(G, W2, None, aux=AUX_RELU_MASK, Hact=H)
+    want = (G.double() @ W2.double().T) * (ref > 0)
+    # entries whose pre-activation is within rounding of zero may flip the mask: exclude |z| < 1e-5
+    sure = (X.double() @ W.double().T).abs() > 1e-5
+    assert float(((D.double() - want) * sure).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("I,K", [(300, 512), (1000, 768), (129, 32)])
+def test_kc_narrow_fp32_output(I, K):
+    g = torch.Generator().manual_seed(I)
+    A = torch.randn(I, K, generator=g)
+    A[:100] *= 1e-5
+    W = torch.randn(9, K, generator=g) * 0.1
+    b = torch.randn(9, generator=g)
+    A, W, b = A.to(DEV), W.to(DEV), b.to(DEV)
+    Cm, _, _ = _kc(A, W, b, narrow=True)
+    ref = A.double() @ W.double().T + b.double()
+    assert float((Cm[:, :9].double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    C0, _, _ = _kc(A, W, None, narrow=True)              # without the bias the quiet rows show their own precision
+    ref0 = A.double() @ W.double().T
+    rows = (C0[:, :9].double() - ref0).norm(dim=1) / ref0.norm(dim=1)
+    assert float(rows.max()) <= 3e-6, float(rows.max())
+
+
+def _dw(A, B, I, J, a_col0=0, b_col0=0, k_split=1024, narrow=False):
+    L, lib = _lib()
+    P = A.shape[0]
+    Cm = torch.full((I, J), float("nan"), device=DEV)
+    lib.check(L.snerf_test_bsp_dw(_p(A), A.shape[1], _p(B), B.shape[1], P, I, J, a_col0, b_col0, k_split, int(narrow), _p(Cm), _st()),
+              "test_bsp_dw")
+    return Cm
+
+
+@pytest.mark.parametrize("P,I,J,ks", [(2048, 256, 256, 1024), (5000, 512, 544, 1024), (650, 256, 64, 128), (20000, 1024, 528, 4096)])
+def test_dw(P, I, J, ks):
+    g = torch.Generator().manual_seed(P + I)
+    A = torch.randn(P, I, generator=g)
+    B = torch.randn(P, J, generator=g)
+    # heavy tail along the contraction axis: blocks of points 2^18 apart
+    scale = torch.ones(P)
+    scale[: P // 3] = 2.0 ** -18
+    scale[P // 3: P // 2] = 2.0 ** 6
+    A = (A * scale[:, None]).to(DEV)
+    B = B.to(DEV)
+    Cm = _dw(A, B, I, J, k_split=ks)
+    ref = A.double().T @ B.double()
+    fp32 = A.T @ B
+    err, err32 = _relerr(Cm, ref), _relerr(fp32, ref)
+    assert err <= max(2.0 * err32, 3e-7), (err, err32)
+
+
+def test_dw_column_offsets_and_narrow():
+    g = torch.Generator().manual_seed(3)
+    P = 3000
+    A = torch.randn(P, 384, generator=g).to(DEV)
+    B = torch.randn(P, 448, generator=g).to(DEV)
+    Cm = _dw(A, B, 256, 320, a_col0=128, b_col0=128)
+    ref = A[:, 128:384].double().T @ B[:, 128:448].double()
+    assert _relerr(Cm, ref) <= max(2.0 * _relerr(A[:, 128:384].T @ B[:, 128:448], ref), 3e-7)
+    An = torch.randn(P, 32, generator=g).to(DEV)
+    An[:1000] *= 1e-6
+    Cn = _dw(An, B, 32, 448, narrow=True)
+    refn = An.double().T @ B.double()
+    assert _relerr(Cn, refn) <= max(2.0 * _relerr(An.T @ B, refn), 3e-7)
+    Cn2 = _dw(An, B, 9, 200, b_col0=192, narrow=True)
+    assert _relerr(Cn2, An[:, :9].double().T @ B[:, 192:392].double()) <= 6e-7
