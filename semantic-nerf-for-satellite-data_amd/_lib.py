@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnerf_hip.so")
+# SNERF_LIB_PATH: an alternative build of the library (ablation harness of tools/ablate; diagnostics only)
+LIB_PATH = os.environ.get("SNERF_LIB_PATH") or os.path.join(_HERE, "libsnerf_hip.so")
 MAX_LAYERS = 16
 ABI_VERSION = 2   # include/snerf_hip.h SNERF_ABI_VERSION
 

@@ -99,6 +99,7 @@ struct KcArgs {
   const char* H = nullptr; const int* EH = nullptr; int ldh = 0; int h_col0 = 0; const unsigned* Hsign = nullptr;
   float* colsum = nullptr; int ldcs = 0;   // per-32-row partial column sums of the stored values (bias gradients)
   int tiles_i = 0, tiles_j = 0;
+  int stagger = 0;                   // first-round workgroups in odd wave slots start this many s_sleep(127) late (launch_kc sets it)
 };
 // sign word of (32-row block, 64-column group, lane) of a tensor with `ld` columns: bit 8 ps + c <-> row (lane >> 3) + 8 ps,
 // column 8 (lane & 7) + c of that block (the epilogue's own lane mapping, so producer and consumer touch one word per lane)

@@ -79,6 +79,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);
   const int i0 = ti * 128, j0 = tj * 256;
   const int nks = p.K >> 4, nks1 = p.Ka >> 4;
+#ifdef BSP_ABL_STAMP
+  const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long sc0 = __builtin_amdgcn_s_memtime();
+#endif
+
+  // Two workgroups share a CU (one wave of each per SIMD).  All tiles take the same time, so two workgroups that start
+  // together stay in lockstep: both in their k-loops (fighting over the matrix pipe), then both in their VALU-heavy
+  // epilogues (matrix pipe idle).  The first round's workgroups in odd wave slots therefore start half a tile late;
+  // every later workgroup inherits the phase of the slot it takes over, and one SIMD's two waves alternate roles.
+  if (p.stagger > 0 && blockIdx.x < 512u) {
+    const unsigned hw_id = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_HW_ID, WAVE_ID = bits 3:0
+    if (hw_id & 1u)
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   // ---- per-lane DMA sources (A: two 1 KiB pieces of the 128 x 64 B stage per wave; B: four pieces of 256 x 64 B)
   const srd_t srdA = make_srd(p.A + ((size_t)i0 * p.lda + p.a_col0) * 4,
@@ -136,11 +150,32 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   const unsigned fo1 = (unsigned)rowl * 64u + (unsigned)(((2 + kh) ^ swz) << 4);
   const unsigned fa_base = (unsigned)wi0 * 64u, fb_base = (unsigned)KC_A + (unsigned)wj0 * 64u;
 
+  // one DMA piece of stage s (q = 0, 1: A; 2 .. 5: B)
+  auto issue1 = [&](int s, int slot, int q) {
+    const bool live = s < nks, seg2 = s >= nks1;
+    char* d = dst0 + slot * KC_STAGE;
+    if (q < 2) dma16(seg2 ? srdA2 : srdA, d + 4096 * q, live ? (seg2 ? voA2[q] : voA[q]) : OOB, (unsigned)(seg2 ? s - nks1 : s) * 64u);
+    else dma16(srdW, d + KC_A + 4096 * (q - 2), live ? voW + 4096u * (q - 2) : OOB, ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_unit0) * 2048u);
+  };
+#ifdef BSP_ABL_STAMP
+  unsigned long long st_wait = 0, st_vm = 0;
+#endif
   auto step = [&](int s, int slot) {
     // stage s has landed for this wave's own pieces once at most the 6 pieces of stage s + 1 are outstanding
+#ifdef BSP_ABL_STAMP
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef BSP_ABL_NODMA
     wait_vm<6>();
+#endif
+#ifdef BSP_ABL_STAMP
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
     barrier_raw();                       // stage s visible to all; everybody has finished reading stage s - 1
-    issue(s + 2, (slot + 2) % KC_RING);  // into the slot stage s - 1 occupied
+#ifdef BSP_ABL_STAMP
+    const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+    st_vm += c1 - c0; st_wait += c2 - c1;
+#endif
     if (__builtin_expect(((s < 64 ? chg0 >> s : chg1 >> (s - 64)) & 1ull) != 0ull, 0)) {
       const int de = etab[s] - etab[s - 1];
 #pragma unroll
@@ -149,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
         for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
     }
     const char* st = lds + slot * KC_STAGE;
-    f16x8 bh[4], bl[4];
+    f16x8 bh[4], bl[4], ah[2], al[2];
 #pragma unroll
     for (int nj = 0; nj < 4; ++nj) {
       bh[nj] = ldsfrag(st + fb_base + 2048 * nj + fo0);
@@ -157,19 +192,69 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-      const f16x8 ah = ldsfrag(st + fa_base + 2048 * mi + fo0);
-      const f16x8 al = ldsfrag(st + fa_base + 2048 * mi + fo1);
-#pragma unroll
-      for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = mfma3(ah, al, bh[nj], bl[nj], acc[mi][nj]);
+      ah[mi] = ldsfrag(st + fa_base + 2048 * mi + fo0);
+      al[mi] = ldsfrag(st + fa_base + 2048 * mi + fo1);
     }
+    // The six pieces of stage s + 2 (into the slot stage s - 1 occupied) go out one per three MFMAs: a DMA issue costs
+    // the wave ~60-100 cycles, which hide under the matrix pipe's 3 x 32 only when the two alternate in program order
+    // (issued in a burst behind the barrier they cost the loop 80 us of 320 per launch: ablation builds, tools/ablate).
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#ifdef BSP_ABL_NOMFMA
+      asm volatile("" ::"v"(ah[mi]), "v"(al[mi]));
+      if (mi == 0) {
+#pragma unroll
+        for (int nj = 0; nj < 4; ++nj) asm volatile("" ::"v"(bh[nj]), "v"(bl[nj]));
+      }
+#else
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = mfma3(ah[mi], al[mi], bh[nj], bl[nj], acc[mi][nj]);
+#endif
+#ifndef BSP_ABL_NODMA
+#pragma unroll
+      for (int q = 0; q < 3; ++q) issue1(s + 2, (slot + 2) % KC_RING, 3 * mi + q);
+#endif
+    }
+#if !defined(BSP_ABL_NOMFMA) && !defined(BSP_ABL_NODMA)
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // the twelve fragment reads
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // 3 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 DMA piece
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#endif
   };
+  // The k-loop runs at raised priority: the SIMD's other wave (the co-resident workgroup) is, half of the time, in its
+  // VALU-heavy epilogue, and at equal priority the older wave wins the shared vector-issue port -- an epilogue stream
+  // then starves this wave's MFMA issue and the matrix pipe idles.  With MFMA issue first, the epilogue wave fills the 24
+  // of every 32 cycles the pipe leaves free.
+  __builtin_amdgcn_s_setprio(2);
   for (int s = 0; s < nks; s += 3) {
     step(s, 0);
     if (s + 1 < nks) step(s + 1, 1);
     if (s + 2 < nks) step(s + 2, 2);
   }
+  __builtin_amdgcn_s_setprio(0);
   wait_vm<0>();        // the two dummy stages behind the last one write zeros into the ring: drain before re-using it
   barrier_raw();
+#ifdef BSP_ABL_STAMP
+  const unsigned long long st1 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long sc1 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef BSP_ABL_NOEPI
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 4; ++nj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += acc[mi][nj][r];
+    if (sum == 12345.678f) p.EC[0] = 1;
+    return;
+  }
+#endif
 
   // ---- epilogue, phase A: final values of the wave's 64 x 128 tile in row layout (8 consecutive columns per lane),
   //      their |max|, column sums; phase B (after the two waves of a 128 x 128 block have exchanged maxima): split + store.
@@ -292,11 +377,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
       const bool ok = col_ok && (i0 + wi0 + rl) < p.I;
       u32x4 hi, lo;
       split8(val[b][ps], sc, hi, lo);
+#ifdef BSP_ABL_NOSTORE
+      const unsigned o = (ok && p.I < 0) ? 0u : OOB;
+#else
       const unsigned o = ok ? (unsigned)rl * (unsigned)p.ldc * 4u + (unsigned)(col >> 4) * 64u + (unsigned)(col & 8) * 2u : OOB;
+#endif
       __builtin_amdgcn_raw_buffer_store_b128(hi, srdC, o, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(lo, srdC, o == OOB ? OOB : o + 32u, 0, 0);
     }
   }
+#ifdef BSP_ABL_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (t == 0 && p.colsum != nullptr) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.colsum) + 8 * (size_t)blockIdx.x;
+    dbg[0] = st0; dbg[1] = st1; dbg[2] = __builtin_amdgcn_s_memrealtime();
+    dbg[3] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));       // HW_REG_HW_ID
+    dbg[4] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));       // HW_REG_XCC_ID
+    dbg[5] = st_vm; dbg[6] = st_wait; dbg[7] = sc1 - sc0;   // shader-clock cycles: in vmcnt waits, in barriers, whole k-loop
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -605,6 +704,9 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   if (rc) return rc;
   a.tiles_i = (a.I + 127) / 128;
   a.tiles_j = (a.J + 255) / 256;
+  static const int stagger_env = getenv("SNERF_KC_STAGGER") ? atoi(getenv("SNERF_KC_STAGGER")) : -1;   // diagnostics: 0 = off
+  // half of a tile's duration, which is proportional to K (measured: ~25 us at K = 512; one s_sleep(127) is ~3.4 us)
+  a.stagger = a.tiles_i * a.tiles_j >= 1024 ? (stagger_env >= 0 ? stagger_env : (a.K + 63) / 128 + 3) : 0;
   const dim3 grid(a.tiles_i * a.tiles_j), block(256);
   const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.K, 0, st);
   const bool cs = a.colsum != nullptr;
