@@ -13,8 +13,9 @@
 //     row block next to a loud one keeps its own 22 bits.  A consumer contracts hi hi + hi lo + lo hi on
 //     v_mfma_f32_32x32x16_f16 (dropped lo lo term: 2^-22 relative) and, where the exponent changes along its
 //     contraction axis, rescales its fp32 accumulators by the power of two (exact).
-// Weights are packed once per step into the K-contiguous GEMM's LDS image ("WP16": 2 KiB units of 32 rows x 16 k,
-// both planes, swizzle baked in) with one exponent per matrix.
+// Weights are packed once per step in MFMA fragment order ("WF16": 2 KiB units of 32 rows x 16 k = [plane][lane][16 B],
+// lane = 32 (k / 8) + row: one fragment is one contiguous KiB that a wave loads straight into registers) with one
+// exponent per matrix.
 #pragma once
 #include "common.h"
 #include "gemm.h"
@@ -84,7 +85,7 @@ struct KcArgs {
   const char* A = nullptr; const int* EA = nullptr; int lda = 0; int a_col0 = 0;      // element (i,k) = column a_col0 + k of the tensor
   const char* A2 = nullptr; const int* EA2 = nullptr; int lda2 = 0; int a2_col0 = 0;
   int Ka = 0;                        // k-length of the first segment (= K when there is no second one); % 16 == 0
-  const char* W = nullptr;           // WP16 pack of the weight matrix; unit (ks, rb32) at ((ks * w_rb32 + rb32) * 2048) bytes
+  const char* W = nullptr;           // WF16 pack of the weight matrix; unit (ks, rb32) at ((ks * w_rb32 + rb32) * 2048) bytes
   const int* EW = nullptr;           // the matrix's exponent (one int, device)
   int w_rb32 = 0, w_row0 = 0, w_k0 = 0; unsigned w_bytes = 0;   // rows / 32 of the pack; first row (% 32 == 0) and first k (% 16 == 0) of the operand
   int I = 0, J = 0, K = 0;           // J % 16 == 0 (BSP output) / J <= 32 (fp32 output); K % 16 == 0
@@ -99,7 +100,6 @@ struct KcArgs {
   const char* H = nullptr; const int* EH = nullptr; int ldh = 0; int h_col0 = 0; const unsigned* Hsign = nullptr;
   float* colsum = nullptr; int ldcs = 0;   // per-32-row partial column sums of the stored values (bias gradients)
   int tiles_i = 0, tiles_j = 0;
-  int stagger = 0;                   // first-round workgroups in odd wave slots start this many s_sleep(127) late (launch_kc sets it)
 };
 // sign word of (32-row block, 64-column group, lane) of a tensor with `ld` columns: bit 8 ps + c <-> row (lane >> 3) + 8 ps,
 // column 8 (lane & 7) + c of that block (the epilogue's own lane mapping, so producer and consumer touch one word per lane)
@@ -124,7 +124,7 @@ int launch_dw(const DwArgs& a, bool narrow_i, hipStream_t st);   // 256 x 256 ti
 int launch_to_planes(const float* src, int ld_src, int rows, int cols, char* dst, int* E, int ld, int col0, hipStream_t st);
 int launch_from_planes(const char* src, const int* E, int ld, int col0, int rows, int cols, float* dst, int ld_dst, hipStream_t st);
 
-struct WPackJob {        // one weight operand: fp32 master matrix (possibly read transposed) -> WP16 pack
+struct WPackJob {        // one weight operand: fp32 master matrix (possibly read transposed) -> WF16 pack
   unsigned long long src_off;   // float offset of the matrix in the packed fp32 region
   int src_ld;                   // its leading dimension
   int rows, K;                  // rows x K of the OPERAND (K % 16 == 0); transposed: operand(r, k) = master(k, r)

@@ -82,8 +82,8 @@ int launch_from_planes(const char* src, const int* E, int ld, int col0, int rows
 
 // ---- weight pack ------------------------------------------------------------------------------------------------------
 // pass 1: |max| of every master matrix (float bits, atomicMax: order-independent); pass 2: every operand (a matrix or its
-// transpose) into WP16 units of 32 rows x 16 k = 2 KiB: row r at r * 64 bytes, chunks {hi k0-7, hi k8-15, lo k0-7,
-// lo k8-15} at position chunk ^ ((r >> 2) & 3) -- the K-contiguous GEMM's LDS image, copied verbatim by its DMA.
+// transpose) into WF16 units of 32 rows x 16 k = 2 KiB = [plane][lane][8 fp16] with lane = 32 (k / 8) + row: the B operand
+// fragment of v_mfma_f32_32x32x16_f16 for 32 output columns, one contiguous KiB per plane.
 __global__ __launch_bounds__(256) void wmax_kernel(WPackTable tb, const float* __restrict__ master, unsigned* __restrict__ maxbits) {
   const WPackJob j = tb.j[blockIdx.y];
   if (j.transposed) return;            // its matrix is covered by the non-transposed job with the same exponent slot
@@ -119,10 +119,9 @@ __global__ __launch_bounds__(256) void wpack_kernel(WPackTable tb, const float* 
     const _Float16 h0 = (_Float16)(x[0] * sc), h1 = (_Float16)(x[1] * sc);
     const _Float16 l0 = (_Float16)(x[0] * sc - (float)h0), l1 = (_Float16)(x[1] * sc - (float)h1);
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    char* u = planes + j.dst_off + (size_t)unit * 2048 + r * 64;
-    const int sw = (r >> 2) & 3;
-    *reinterpret_cast<f16x2*>(u + ((((kp >> 3) + 0) ^ sw) << 4) + (kp & 7) * 2) = f16x2{h0, h1};
-    *reinterpret_cast<f16x2*>(u + ((((kp >> 3) + 2) ^ sw) << 4) + (kp & 7) * 2) = f16x2{l0, l1};
+    char* u = planes + j.dst_off + (size_t)unit * 2048 + (32 * (kp >> 3) + r) * 16 + (kp & 7) * 2;
+    *reinterpret_cast<f16x2*>(u) = f16x2{h0, h1};
+    *reinterpret_cast<f16x2*>(u + 1024) = f16x2{l0, l1};
   }
 }
 

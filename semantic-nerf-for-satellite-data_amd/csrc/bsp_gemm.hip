@@ -60,10 +60,24 @@ __device__ __forceinline__ int kc_exp_of_step(const KcArgs& p, int rb, int s, in
 // ------------------------------------------------------------------------------------------------------------------
 // K-contiguous GEMM, BSP output
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int KC_A = 128 * 64, KC_B = 256 * 64, KC_STAGE = KC_A + KC_B, KC_RING = 3;
+// 128 x 256 tile, four waves side by side: wave w owns ALL 128 rows and columns 64 w .. 64 w + 63 (acc[4][2]).
+//   A (activations, streamed once from HBM): LDS-DMA ring of 16-deep stages, read by every wave (8 ds_read_b128 / step).
+//   W (weights, L2-resident, packed in fragment order "WF16"): each wave loads ITS OWN four fragments of the next step
+//     straight into registers (4 x buffer_load_dwordx4, 1 KiB contiguous each) -- no LDS round trip, no DMA, no sharing
+//     needed because the waves split the columns.
+// Measured on the first form of this kernel (both operands through LDS, waves 2 x 2): the LDS array was busy 66 % of the
+// time (fragment reads + DMA fills, 144 KB per step of two co-resident workgroups) and the six DMA pieces per wave and
+// step cost the issuing wave ~80 cycles each (ablation builds of tools/ablate: 72 of 460 us per launch); the weight
+// tiles were 2/3 of both.  This form moves 80 KB per step through LDS and issues two pieces per wave.
+constexpr int KC_A = 128 * 64, KC_RING = 4;
 constexpr int KC_STRIP = 32 * 68 * 4;                      // one wave's 32 x (64 + 4) fp32 transposition strip
-constexpr int KC_TAIL = KC_RING * KC_STAGE;                // small tables behind the ring
+constexpr int KC_RINGB = KC_RING * KC_A;                   // 32 KiB
+constexpr int KC_TAIL = (KC_RINGB > 4 * KC_STRIP) ? KC_RINGB : 4 * KC_STRIP;   // small tables behind ring / strips
+#ifdef BSP_ABL_ONEWG
+constexpr int KC_LDS = KC_TAIL + 128 * 4 + 64 + 64 * 1024;   // one workgroup per CU (diagnostics)
+#else
 constexpr int KC_LDS = KC_TAIL + 128 * 4 + 64;
+#endif
 
 template <int ACT, int AUX, bool COLSUM>
 __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
@@ -73,8 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wr = wave >> 1, wc = wave & 1;
-  const int wi0 = wr * 64, wj0 = wc * 128;
+  const int wj0 = wave * 64;
   int ti, tj;
   tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);
   const int i0 = ti * 128, j0 = tj * 256;
@@ -84,22 +97,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   const unsigned long long sc0 = __builtin_amdgcn_s_memtime();
 #endif
 
-  // Two workgroups share a CU (one wave of each per SIMD).  All tiles take the same time, so two workgroups that start
-  // together stay in lockstep: both in their k-loops (fighting over the matrix pipe), then both in their VALU-heavy
-  // epilogues (matrix pipe idle).  The first round's workgroups in odd wave slots therefore start half a tile late;
-  // every later workgroup inherits the phase of the slot it takes over, and one SIMD's two waves alternate roles.
-  if (p.stagger > 0 && blockIdx.x < 512u) {
-    const unsigned hw_id = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_HW_ID, WAVE_ID = bits 3:0
-    if (hw_id & 1u)
-      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-
-  // ---- per-lane DMA sources (A: two 1 KiB pieces of the 128 x 64 B stage per wave; B: four pieces of 256 x 64 B)
+  // ---- A: per-lane DMA sources (two 1 KiB pieces of the 128 x 64 B stage per wave)
   const srd_t srdA = make_srd(p.A + ((size_t)i0 * p.lda + p.a_col0) * 4,
                               clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda + p.Ka) * 4ull : 0ull));
   const srd_t srdA2 = make_srd(p.A2 + ((size_t)i0 * p.lda2 + p.a2_col0) * 4,
                                clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda2 + (p.K - p.Ka)) * 4ull : 0ull));
-  const srd_t srdW = make_srd(p.W, p.w_bytes);
   unsigned voA[2], voA2[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -109,69 +111,73 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
     voA[q] = in ? (unsigned)row * (unsigned)p.lda * 4u + 16u * c : OOB;
     voA2[q] = in ? (unsigned)row * (unsigned)p.lda2 * 4u + 16u * c : OOB;
   }
-  const unsigned voW = 16u * (unsigned)t;
-  const unsigned w_unit0 = (unsigned)((p.w_row0 + j0) >> 5), w_ks0 = (unsigned)(p.w_k0 >> 4);
   char* const dst0 = lds + wave * 1024;
-  auto issue = [&](int s, int slot) {
+  auto issueA = [&](int s, int slot, int q) {
     const bool live = s < nks, seg2 = s >= nks1;
-    const srd_t sa = seg2 ? srdA2 : srdA;
-    const unsigned so = (unsigned)(seg2 ? s - nks1 : s) * 64u;
-    char* d = dst0 + slot * KC_STAGE;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) dma16(sa, d + 4096 * q, live ? (seg2 ? voA2[q] : voA[q]) : OOB, so);
-    const unsigned sw = ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_unit0) * 2048u;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dma16(srdW, d + KC_A + 4096 * q, live ? voW + 4096u * q : OOB, sw);
+    dma16(seg2 ? srdA2 : srdA, dst0 + slot * KC_A + 4096 * q, live ? (seg2 ? voA2[q] : voA[q]) : OOB, (unsigned)(seg2 ? s - nks1 : s) * 64u);
   };
+  // ---- W: fragment-ordered pack; unit (ks, rb32) = 2 KiB = [plane][lane][16 B]; this wave reads units rb32 = u0, u0 + 1
+  const srd_t srdW = make_srd(p.W, p.w_bytes);
+  const unsigned w_u0 = (unsigned)((p.w_row0 + j0 + wj0) >> 5), w_ks0 = (unsigned)(p.w_k0 >> 4);
+  const unsigned voW = 16u * (unsigned)lane;
+  struct BFrag { u32x4 h[2], l[2]; };
+  auto loadB = [&](int s, BFrag& b) {
+    const unsigned so = ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_u0) * 2048u;
+    const unsigned vo = s < nks ? voW : OOB;
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj) {
+      b.h[nj] = __builtin_amdgcn_raw_buffer_load_b128(srdW, vo == OOB ? OOB : vo + 2048u * nj, so, 0);
+      b.l[nj] = __builtin_amdgcn_raw_buffer_load_b128(srdW, vo == OOB ? OOB : vo + 2048u * nj + 1024u, so, 0);
+    }
+  };
+
   // ---- exponents along k: table in LDS + a bit per step where the scale changes (128 steps at most: K <= 2048).
-  // The loads go out first and are consumed behind the first two stage requests (their wait then counts past the DMA).
+  // The loads go out first and are consumed behind the first stage requests (their wait then counts past the DMA).
   const int sA = lane, sB = lane + 64;
   const int eA = sA < nks ? kc_exp_of_step(p, ti, sA, nks1) : 0;
   const int eB = sB < nks ? kc_exp_of_step(p, ti, sB, nks1) : 0;
   const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti, sA - 1, nks1) : eA;
   const int eBp = sB < nks ? kc_exp_of_step(p, ti, sB - 1, nks1) : eB;
   const int e_last = kc_exp_of_step(p, ti, nks - 1, nks1);
-  issue(0, 0);
-  issue(1, 1);
+  // vm-counter order from here on: [A(0) A(1)] [W(0)] then per step s: [W(s + 1)] [A(s + 2)] -- at the top of step s the
+  // two pieces of A(s + 1) are the only requests allowed to be outstanding: s_waitcnt vmcnt(2)
+  issueA(0, 0, 0); issueA(0, 0, 1);
+  BFrag bq0, bq1;
+  loadB(0, bq0);
+  issueA(1, 1, 0); issueA(1, 1, 1);
   if (wave == 0) { etab[sA] = eA; etab[sB] = eB; }
   const unsigned long long chg0 = __builtin_amdgcn_ballot_w64(eA != eAp), chg1 = __builtin_amdgcn_ballot_w64(eB != eBp);
 
-  f32x16 acc[2][4];
+  f32x16 acc[4][2];
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi)
+  for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int nj = 0; nj < 4; ++nj)
+    for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
 
-  // fragment addresses: lane -> (row l & 31, k half l >> 5); chunk (2 pl + half) sits at position chunk ^ ((row >> 2) & 3)
+  // A fragment addresses: lane -> (row l & 31, k half l >> 5); chunk (2 pl + half) sits at position chunk ^ ((row >> 2) & 3)
   const int rowl = lane & 31, kh = lane >> 5, swz = (rowl >> 2) & 3;
   const unsigned fo0 = (unsigned)rowl * 64u + (unsigned)(((0 + kh) ^ swz) << 4);
   const unsigned fo1 = (unsigned)rowl * 64u + (unsigned)(((2 + kh) ^ swz) << 4);
-  const unsigned fa_base = (unsigned)wi0 * 64u, fb_base = (unsigned)KC_A + (unsigned)wj0 * 64u;
 
-  // one DMA piece of stage s (q = 0, 1: A; 2 .. 5: B)
-  auto issue1 = [&](int s, int slot, int q) {
-    const bool live = s < nks, seg2 = s >= nks1;
-    char* d = dst0 + slot * KC_STAGE;
-    if (q < 2) dma16(seg2 ? srdA2 : srdA, d + 4096 * q, live ? (seg2 ? voA2[q] : voA[q]) : OOB, (unsigned)(seg2 ? s - nks1 : s) * 64u);
-    else dma16(srdW, d + KC_A + 4096 * (q - 2), live ? voW + 4096u * (q - 2) : OOB, ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_unit0) * 2048u);
-  };
 #ifdef BSP_ABL_STAMP
   unsigned long long st_wait = 0, st_vm = 0;
 #endif
-  auto step = [&](int s, int slot) {
-    // stage s has landed for this wave's own pieces once at most the 6 pieces of stage s + 1 are outstanding
+  // one k-step: MFMAs of step s on (LDS slot, weight registers `bc`); `bn` receives the weight fragments of step s + 1
+  auto step = [&](int s, int slot, const BFrag& bc, BFrag& bn) {
 #ifdef BSP_ABL_STAMP
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
-#ifndef BSP_ABL_NODMA
-    wait_vm<6>();
+#if defined(BSP_ABL_NODMA) || defined(BSP_ABL_NOBLOAD)
+    wait_vm<0>();
+#else
+    wait_vm<2>();
 #endif
 #ifdef BSP_ABL_STAMP
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
-    barrier_raw();                       // stage s visible to all; everybody has finished reading stage s - 1
+    barrier_raw();                       // stage s visible to all; everybody has finished reading stage s - 2
 #ifdef BSP_ABL_STAMP
     const unsigned long long c2 = __builtin_amdgcn_s_memtime();
     st_vm += c1 - c0; st_wait += c2 - c1;
@@ -179,64 +185,62 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
     if (__builtin_expect(((s < 64 ? chg0 >> s : chg1 >> (s - 64)) & 1ull) != 0ull, 0)) {
       const int de = etab[s] - etab[s - 1];
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
+        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
     }
-    const char* st = lds + slot * KC_STAGE;
-    f16x8 bh[4], bl[4], ah[2], al[2];
+#ifndef BSP_ABL_NOBLOAD
+    loadB(s + 1, bn);
+#endif
+    const char* st = lds + slot * KC_A;
+    f16x8 ah[4], al[4];
 #pragma unroll
-    for (int nj = 0; nj < 4; ++nj) {
-      bh[nj] = ldsfrag(st + fb_base + 2048 * nj + fo0);
-      bl[nj] = ldsfrag(st + fb_base + 2048 * nj + fo1);
+    for (int mi = 0; mi < 4; ++mi) {
+#ifdef BSP_ABL_NOLDSREAD
+      ah[mi] = __builtin_bit_cast(f16x8, bc.h[mi & 1]); al[mi] = __builtin_bit_cast(f16x8, bc.l[mi & 1]);
+#else
+      ah[mi] = ldsfrag(st + 2048 * mi + fo0);
+      al[mi] = ldsfrag(st + 2048 * mi + fo1);
+#endif
     }
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-      ah[mi] = ldsfrag(st + fa_base + 2048 * mi + fo0);
-      al[mi] = ldsfrag(st + fa_base + 2048 * mi + fo1);
-    }
-    // The six pieces of stage s + 2 (into the slot stage s - 1 occupied) go out one per three MFMAs: a DMA issue costs
-    // the wave ~60-100 cycles, which hide under the matrix pipe's 3 x 32 only when the two alternate in program order
-    // (issued in a burst behind the barrier they cost the loop 80 us of 320 per launch: ablation builds, tools/ablate).
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < 4; ++mi) {
 #ifdef BSP_ABL_NOMFMA
-      asm volatile("" ::"v"(ah[mi]), "v"(al[mi]));
-      if (mi == 0) {
-#pragma unroll
-        for (int nj = 0; nj < 4; ++nj) asm volatile("" ::"v"(bh[nj]), "v"(bl[nj]));
-      }
+      asm volatile("" ::"v"(ah[mi]), "v"(al[mi]), "v"(bc.h[0]), "v"(bc.l[0]), "v"(bc.h[1]), "v"(bc.l[1]));
 #else
 #pragma unroll
-      for (int nj = 0; nj < 4; ++nj) acc[mi][nj] = mfma3(ah[mi], al[mi], bh[nj], bl[nj], acc[mi][nj]);
+      for (int nj = 0; nj < 2; ++nj)
+        acc[mi][nj] = mfma3(ah[mi], al[mi], __builtin_bit_cast(f16x8, bc.h[nj]), __builtin_bit_cast(f16x8, bc.l[nj]), acc[mi][nj]);
 #endif
 #ifndef BSP_ABL_NODMA
-#pragma unroll
-      for (int q = 0; q < 3; ++q) issue1(s + 2, (slot + 2) % KC_RING, 3 * mi + q);
+      if (mi == 1) issueA(s + 2, (slot + 2) % KC_RING, 0);   // the two pieces of stage s + 2, under the MFMAs
+      if (mi == 2) issueA(s + 2, (slot + 2) % KC_RING, 1);
 #endif
     }
-#if !defined(BSP_ABL_NOMFMA) && !defined(BSP_ABL_NODMA)
-    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);   // the twelve fragment reads
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // 3 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 DMA piece
-    }
+#if !defined(BSP_ABL_NOBLOAD) && !defined(BSP_ABL_NOLDSREAD) && !defined(BSP_ABL_NOMFMA) && !defined(BSP_ABL_NODMA)
+    // pin the order in the emitted code: the weight loads of step s + 1 go out FIRST (left alone, the scheduler sinks them
+    // to the end of the step to save registers and the next step then waits for L2 with nothing to do), then the eight
+    // fragment reads, then the MFMAs with the two DMA pieces in between
+    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
 #endif
   };
-  // The k-loop runs at raised priority: the SIMD's other wave (the co-resident workgroup) is, half of the time, in its
-  // VALU-heavy epilogue, and at equal priority the older wave wins the shared vector-issue port -- an epilogue stream
-  // then starves this wave's MFMA issue and the matrix pipe idles.  With MFMA issue first, the epilogue wave fills the 24
-  // of every 32 cycles the pipe leaves free.
+  // The k-loop runs at raised priority: while the SIMD's other wave (the co-resident workgroup) is in its VALU-heavy
+  // epilogue, MFMA issue goes first and the epilogue stream fills the 24 of every 32 cycles the matrix pipe leaves free.
   __builtin_amdgcn_s_setprio(2);
-  for (int s = 0; s < nks; s += 3) {
-    step(s, 0);
-    if (s + 1 < nks) step(s + 1, 1);
-    if (s + 2 < nks) step(s + 2, 2);
+  for (int s = 0; s < nks; s += 4) {
+    step(s, 0, bq0, bq1);
+    if (s + 1 < nks) step(s + 1, 1, bq1, bq0);
+    if (s + 2 < nks) step(s + 2, 2, bq0, bq1);
+    if (s + 3 < nks) step(s + 3, 3, bq1, bq0);
   }
   __builtin_amdgcn_s_setprio(0);
-  wait_vm<0>();        // the two dummy stages behind the last one write zeros into the ring: drain before re-using it
+  wait_vm<0>();        // rejected requests behind the last stage write zeros into the ring: drain before re-using it
   barrier_raw();
 #ifdef BSP_ABL_STAMP
   const unsigned long long st1 = __builtin_amdgcn_s_memrealtime();
@@ -246,9 +250,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   {
     float sum = 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int nj = 0; nj < 4; ++nj)
+      for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sum += acc[mi][nj][r];
     if (sum == 12345.678f) p.EC[0] = 1;
@@ -256,50 +260,57 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   }
 #endif
 
-  // ---- epilogue, phase A: final values of the wave's 64 x 128 tile in row layout (8 consecutive columns per lane),
+  // ---- epilogue, phase A: final values of the wave's 128 x 64 tile in row layout (8 consecutive columns per lane),
   //      their |max|, column sums; phase B (after the two waves of a 128 x 128 block have exchanged maxima): split + store.
   const int e_in = e_last + *p.EW;          // acc = true value * 2^e_in
+  const bool e_small = e_in >= -120 && e_in <= 120;
+  const float inv_in = e_small ? pow2f(-e_in) : 1.f;
   float* strip = reinterpret_cast<float*>(lds + wave * KC_STRIP);
   const int lc = lane & 31, lh = lane >> 5;
   const int rrow = lane >> 3, c8 = (lane & 7) * 8;
+  const int col = j0 + wj0 + c8;
+  const bool col_ok = col < p.J;
   float val[4][4][8];
   float wmax = 0.f;
   int eH = 0;
   if (AUX != AUX_NONE && j0 + wj0 < p.J) eH = p.EH[(size_t)ti * ncb_of(p.ldh) + ((p.h_col0 + j0 + wj0) >> 7)];
   const float inv_h = pow2f(-eH);
-  const size_t offH = uniform_sz(((size_t)(i0 + wi0) * p.ldh + p.h_col0) * 4);
+  const size_t offH = uniform_sz(((size_t)i0 * p.ldh + p.h_col0) * 4);
   const srd_t srdH = make_srd(AUX != AUX_NONE ? p.H + offH : nullptr, AUX != AUX_NONE ? 0xFFFFFFE0u : 0u);
+  float bj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (p.bias != nullptr && col_ok) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+    bj[0] = b0.x; bj[1] = b0.y; bj[2] = b0.z; bj[3] = b0.w; bj[4] = b1.x; bj[5] = b1.y; bj[6] = b1.z; bj[7] = b1.w;
+  }
+  if (!e_small) {   // exponents beyond a single fp32 factor (never with sane data): scale the accumulators first
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    const int mi = b >> 1, hj = b & 1;
-    const int rbase = i0 + wi0 + 32 * mi, col = j0 + wj0 + 64 * hj + c8;
-    const bool col_ok = col < p.J;
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], -e_in);
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {          // 32-row blocks of the wave tile
+    const int rbase = i0 + 32 * b;
     u32x4 hh[AUX != AUX_NONE ? 4 : 1], hl[AUX != AUX_NONE ? 4 : 1];
     unsigned sword = 0u;
     if (AUX != AUX_NONE) {
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
-        const int rl = 32 * mi + rrow + 8 * ps;
-        const bool ok = col_ok && (i0 + wi0 + rl) < p.I;
+        const int rl = 32 * b + rrow + 8 * ps;
+        const bool ok = col_ok && (i0 + rl) < p.I;
         const unsigned o = ok ? (unsigned)rl * (unsigned)p.ldh * 4u + (unsigned)(col >> 4) * 64u + (unsigned)(col & 8) * 2u : OOB;
         hh[ps] = __builtin_amdgcn_raw_buffer_load_b128(srdH, o, 0, 0);
         hl[ps] = __builtin_amdgcn_raw_buffer_load_b128(srdH, o == OOB ? OOB : o + 32u, 0, 0);
       }
       if (AUX == AUX_SINREC) {
-        const size_t sidx = ((size_t)(rbase >> 5) * ((p.ldh + 63) >> 6) + ((p.h_col0 + col - c8) >> 6)) * 64 + lane;
+        const size_t sidx = ((size_t)(rbase >> 5) * ((p.ldh + 63) >> 6) + ((p.h_col0 + j0 + wj0) >> 6)) * 64 + lane;
         sword = p.Hsign[(col_ok && rbase < p.I) ? sidx : 0];
       }
-    }
-    float bj[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (p.bias != nullptr && col_ok) {
-      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
-      bj[0] = b0.x; bj[1] = b0.y; bj[2] = b0.z; bj[3] = b0.w; bj[4] = b1.x; bj[5] = b1.y; bj[6] = b1.z; bj[7] = b1.w;
     }
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + 32 * n + lc] = __builtin_amdgcn_ldexpf(acc[mi][2 * hj + n][r], -e_in);
+      for (int r = 0; r < 16; ++r) strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + 32 * n + lc] = acc[b][n][r];
     unsigned sbits = 0u;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -307,7 +318,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
       const bool ok = col_ok && (rbase + rrow + 8 * ps) < p.I;
       const float4 x0 = *reinterpret_cast<const float4*>(&strip[(rrow + 8 * ps) * 68 + c8]);
       const float4 x1 = *reinterpret_cast<const float4*>(&strip[(rrow + 8 * ps) * 68 + c8 + 4]);
-      float v[8] = {x0.x + bj[0], x0.y + bj[1], x0.z + bj[2], x0.w + bj[3], x1.x + bj[4], x1.y + bj[5], x1.z + bj[6], x1.w + bj[7]};
+      const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = fmaf(x[c], inv_in, bj[c]);      // exact power of two, then + bias
       if (ACT == ACT_SIN) {
         unsigned n0, n1;
         const float4 s0 = sin4_signcos(make_float4(p.w0 * v[0], p.w0 * v[1], p.w0 * v[2], p.w0 * v[3]), &n0);
@@ -336,13 +350,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         v[c] = ok ? v[c] : 0.f;
-        wmax = fmaxf(wmax, fabsf(v[c]));
         if (COLSUM) cs[c] += v[c];
         val[b][ps][c] = v[c];
       }
+      wmax = fmaxf(wmax, fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
+                               fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7])))));
     }
     if (ACT == ACT_SIN && p.Csign != nullptr && col_ok && rbase < p.I)
-      p.Csign[((size_t)(rbase >> 5) * ((p.ldc + 63) >> 6) + ((p.c_col0 + col - c8) >> 6)) * 64 + lane] = sbits;
+      p.Csign[((size_t)(rbase >> 5) * ((p.ldc + 63) >> 6) + ((p.c_col0 + j0 + wj0) >> 6)) * 64 + lane] = sbits;
     if (COLSUM && p.colsum != nullptr) {
 #pragma unroll
       for (int o = 8; o < 64; o <<= 1)
@@ -355,26 +370,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
       }
     }
   }
-  // block maximum: the waves (0, wc) and (1, wc) share the exponent block (ti, column block of wc)
+  // block maximum: waves 2 c and 2 c + 1 share the exponent block (ti, column block c of the tile)
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
   if (lane == 0) smax[wave] = wmax;
   __syncthreads();
-  const float bmax = fmaxf(smax[wc], smax[2 + wc]);
+  const float bmax = fmaxf(smax[wave & 2], smax[(wave & 2) + 1]);
   const int eC = exp_of_maxbits(__float_as_uint(bmax));
   const float sc = pow2f(eC);
-  if (wr == 0 && lane == 0 && j0 + wj0 < p.J) p.EC[(size_t)ti * ncb_of(p.ldc) + ((p.c_col0 + j0 + wj0) >> 7)] = eC;
-  const size_t offC = uniform_sz(((size_t)(i0 + wi0) * p.ldc + p.c_col0) * 4);
+  if ((wave & 1) == 0 && lane == 0 && j0 + wj0 < p.J) p.EC[(size_t)ti * ncb_of(p.ldc) + ((p.c_col0 + j0 + wj0) >> 7)] = eC;
+  const size_t offC = uniform_sz(((size_t)i0 * p.ldc + p.c_col0) * 4);
   const srd_t srdC = make_srd(p.C + offC, 0xFFFFFFE0u);
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    const int mi = b >> 1, hj = b & 1;
-    const int col = j0 + wj0 + 64 * hj + c8;
-    const bool col_ok = col < p.J;
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
-      const int rl = 32 * mi + rrow + 8 * ps;
-      const bool ok = col_ok && (i0 + wi0 + rl) < p.I;
+      const int rl = 32 * b + rrow + 8 * ps;
+      const bool ok = col_ok && (i0 + rl) < p.I;
       u32x4 hi, lo;
       split8(val[b][ps], sc, hi, lo);
 #ifdef BSP_ABL_NOSTORE
@@ -400,9 +412,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 
 // ------------------------------------------------------------------------------------------------------------------
 // K-contiguous GEMM, 32-wide fp32 output (pre-activations of sigma / sun visibility / final head layers: the composite
-// kernels apply their activations).  128 x 32 tile, four waves of 32 x 32.
+// kernels apply their activations).  128 x 32 tile, four waves of 32 x 32; the weight fragments (one 32-row unit, the
+// same for every wave) come straight from L2 as above.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int KN_A = 128 * 64, KN_B = 32 * 64, KN_STAGE = KN_A + KN_B, KN_TAIL = 3 * KN_STAGE, KN_DUMMY = KN_TAIL + 512, KN_LDS = KN_DUMMY + 2048;
+constexpr int KN_A = 128 * 64, KN_RING = 4, KN_TAIL = KN_RING * KN_A, KN_LDS = KN_TAIL + 512;
 
 __global__ __launch_bounds__(256, 4) void gemm_kcn_kernel(const KcArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[KN_LDS];
@@ -421,17 +434,17 @@ __global__ __launch_bounds__(256, 4) void gemm_kcn_kernel(const KcArgs p) {
     const unsigned c = (unsigned)((t & 3) ^ ((row >> 2) & 3));
     voA[q] = (i0 + row < p.I) ? (unsigned)row * (unsigned)p.lda * 4u + 16u * c : OOB;
   }
-  // the 2 KiB weight stage is two pieces: waves 0 and 1 fetch one each; waves 2 and 3 issue a rejected (zero-traffic)
-  // piece into a scratch KiB of their own so that every wave counts three pieces per stage
-  const unsigned voW = wave < 2 ? 16u * (unsigned)t : OOB;
-  const unsigned w_unit0 = (unsigned)(p.w_row0 >> 5), w_ks0 = (unsigned)(p.w_k0 >> 4);
-  auto issue = [&](int s, int slot) {
-    const bool live = s < nks;
-    char* d = lds + slot * KN_STAGE;
-    const unsigned sw = ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_unit0) * 2048u;
-    dma16(srdW, wave < 2 ? d + KN_A + wave * 1024 : lds + KN_DUMMY + (wave - 2) * 1024, live ? voW : OOB, sw);
+  const unsigned w_u0 = (unsigned)(p.w_row0 >> 5), w_ks0 = (unsigned)(p.w_k0 >> 4);
+  auto issueA = [&](int s, int slot) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) dma16(srdA, d + 4096 * q + wave * 1024, live ? voA[q] : OOB, (unsigned)s * 64u);
+    for (int q = 0; q < 2; ++q) dma16(srdA, lds + slot * KN_A + 4096 * q + wave * 1024, s < nks ? voA[q] : OOB, (unsigned)s * 64u);
+  };
+  struct BFrag { u32x4 h, l; };
+  auto loadB = [&](int s, BFrag& b) {
+    const unsigned so = ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_u0) * 2048u;
+    const unsigned vo = s < nks ? 16u * (unsigned)lane : OOB;
+    b.h = __builtin_amdgcn_raw_buffer_load_b128(srdW, vo, so, 0);
+    b.l = __builtin_amdgcn_raw_buffer_load_b128(srdW, vo == OOB ? OOB : vo + 1024u, so, 0);
   };
   const int sA = lane, sB = lane + 64;
   const int eA = sA < nks ? kc_exp_of_step(p, ti, sA, nks1) : 0;
@@ -439,8 +452,10 @@ __global__ __launch_bounds__(256, 4) void gemm_kcn_kernel(const KcArgs p) {
   const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti, sA - 1, nks1) : eA;
   const int eBp = sB < nks ? kc_exp_of_step(p, ti, sB - 1, nks1) : eB;
   const int e_last = kc_exp_of_step(p, ti, nks - 1, nks1);
-  issue(0, 0);
-  issue(1, 1);
+  issueA(0, 0);
+  BFrag bq0, bq1;
+  loadB(0, bq0);
+  issueA(1, 1);
   if (wave == 0) { etab[sA] = eA; etab[sB] = eB; }
   const unsigned long long chg0 = __builtin_amdgcn_ballot_w64(eA != eAp), chg1 = __builtin_amdgcn_ballot_w64(eB != eBp);
   f32x16 acc;
@@ -449,18 +464,20 @@ __global__ __launch_bounds__(256, 4) void gemm_kcn_kernel(const KcArgs p) {
   const int rowl = lane & 31, kh = lane >> 5, swz = (rowl >> 2) & 3;
   const unsigned fo0 = (unsigned)rowl * 64u + (unsigned)(((0 + kh) ^ swz) << 4);
   const unsigned fo1 = (unsigned)rowl * 64u + (unsigned)(((2 + kh) ^ swz) << 4);
-  auto step = [&](int s, int slot) {
-    wait_vm<3>();
+  auto step = [&](int s, int slot, const BFrag& bc, BFrag& bn) {
+    wait_vm<2>();
     barrier_raw();
-    issue(s + 2, (slot + 2) % 3);
     if (__builtin_expect(((s < 64 ? chg0 >> s : chg1 >> (s - 64)) & 1ull) != 0ull, 0)) acc = scale_acc(acc, etab[s] - etab[s - 1]);
-    const char* st = lds + slot * KN_STAGE;
-    acc = mfma3(ldsfrag(st + wi0 * 64 + fo0), ldsfrag(st + wi0 * 64 + fo1), ldsfrag(st + KN_A + fo0), ldsfrag(st + KN_A + fo1), acc);
+    loadB(s + 1, bn);
+    issueA(s + 2, (slot + 2) % KN_RING);
+    const char* st = lds + slot * KN_A;
+    acc = mfma3(ldsfrag(st + wi0 * 64 + fo0), ldsfrag(st + wi0 * 64 + fo1), __builtin_bit_cast(f16x8, bc.h), __builtin_bit_cast(f16x8, bc.l), acc);
   };
-  for (int s = 0; s < nks; s += 3) {
-    step(s, 0);
-    if (s + 1 < nks) step(s + 1, 1);
-    if (s + 2 < nks) step(s + 2, 2);
+  for (int s = 0; s < nks; s += 4) {
+    step(s, 0, bq0, bq1);
+    if (s + 1 < nks) step(s + 1, 1, bq1, bq0);
+    if (s + 2 < nks) step(s + 2, 2, bq0, bq1);
+    if (s + 3 < nks) step(s + 3, 3, bq1, bq0);
   }
   wait_vm<0>();
   const int e_in = e_last + *p.EW;
@@ -704,9 +721,6 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   if (rc) return rc;
   a.tiles_i = (a.I + 127) / 128;
   a.tiles_j = (a.J + 255) / 256;
-  static const int stagger_env = getenv("SNERF_KC_STAGGER") ? atoi(getenv("SNERF_KC_STAGGER")) : -1;   // diagnostics: 0 = off
-  // half of a tile's duration, which is proportional to K (measured: ~25 us at K = 512; one s_sleep(127) is ~3.4 us)
-  a.stagger = a.tiles_i * a.tiles_j >= 1024 ? (stagger_env >= 0 ? stagger_env : (a.K + 63) / 128 + 3) : 0;
   const dim3 grid(a.tiles_i * a.tiles_j), block(256);
   const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.K, 0, st);
   const bool cs = a.colsum != nullptr;

@@ -11,12 +11,8 @@ build() {  # name, macros...
   /opt/rocm/bin/hipcc $FLAGS "$@" -c bsp_gemm.hip -o /tmp/bsp_gemm_$name.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsnerf_hip_$name.so gemm.o gemm_x6.o /tmp/bsp_gemm_$name.o bsp_aux.o aux_kernels.o composite.o loss.o optim.o api.o
 }
-build nostore -DBSP_ABL_NOSTORE &
 build stamp -DBSP_ABL_STAMP &
-build stampnodma -DBSP_ABL_STAMP -DBSP_ABL_NODMA &
-build stampnomfma -DBSP_ABL_STAMP -DBSP_ABL_NOMFMA &
-build noepi -DBSP_ABL_NOEPI &
-build nodma -DBSP_ABL_NOEPI -DBSP_ABL_NODMA &
-build nomfma -DBSP_ABL_NOEPI -DBSP_ABL_NOMFMA &
+build stamp1wg -DBSP_ABL_STAMP -DBSP_ABL_ONEWG &
+build onewg -DBSP_ABL_ONEWG &
 wait
 ls -la $OUT/*.so
