@@ -30,6 +30,24 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 __device__ __forceinline__ void dma16(srd_t srd, char* lds_dst, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
 }
+// The same request as an asm statement the compiler cannot see into.  hipcc models the builtin form as a store to LDS and,
+// where its alias analysis cannot separate the destination from a following LDS read (the dW kernel's transposed reads),
+// puts s_waitcnt vmcnt(0) between them -- every stage request is then drained right after it is issued and the whole
+// DMA latency sits on the critical path of every k-step (measured: 452 -> see DESIGN for the dW launch).  Completion is
+// tracked by the kernels' own counted waits either way.  M0 (the LDS destination) is saved and restored inside.
+typedef unsigned int srd_words __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ srd_words make_srd_words(const void* p, unsigned bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  return srd_words{(unsigned)__builtin_amdgcn_readfirstlane((unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu),
+                   (unsigned)__builtin_amdgcn_readfirstlane(bytes), 0x00020000u};
+}
+__device__ __forceinline__ void dma16_asm(srd_words srd, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_byte_addr), "v"(voff), "s"(srd), "s"(soff));
+}
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(unsigned long long)(lds_ptr_t)const_cast<char*>(p); }
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ void barrier_raw() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -69,7 +87,7 @@ __device__ __forceinline__ int kc_exp_of_step(const KcArgs& p, int rb, int s, in
 // time (fragment reads + DMA fills, 144 KB per step of two co-resident workgroups) and the six DMA pieces per wave and
 // step cost the issuing wave ~80 cycles each (ablation builds of tools/ablate: 72 of 460 us per launch); the weight
 // tiles were 2/3 of both.  This form moves 80 KB per step through LDS and issues two pieces per wave.
-constexpr int KC_A = 128 * 64, KC_RING = 4;
+constexpr int KC_A = 128 * 64, KC_RING = 3;
 constexpr int KC_STRIP = 32 * 68 * 4;                      // one wave's 32 x (64 + 4) fp32 transposition strip
 constexpr int KC_RINGB = KC_RING * KC_A;                   // 32 KiB
 constexpr int KC_TAIL = (KC_RINGB > 4 * KC_STRIP) ? KC_RINGB : 4 * KC_STRIP;   // small tables behind ring / strips
@@ -114,21 +132,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   char* const dst0 = lds + wave * 1024;
   auto issueA = [&](int s, int slot, int q) {
     const bool live = s < nks, seg2 = s >= nks1;
-    dma16(seg2 ? srdA2 : srdA, dst0 + slot * KC_A + 4096 * q, live ? (seg2 ? voA2[q] : voA[q]) : OOB, (unsigned)(seg2 ? s - nks1 : s) * 64u);
+    dma16(seg2 ? srdA2 : srdA, dst0 + slot * KC_A + 4096 * q, seg2 ? voA2[q] : voA[q], live ? (unsigned)(seg2 ? s - nks1 : s) * 64u : OOB);
   };
   // ---- W: fragment-ordered pack; unit (ks, rb32) = 2 KiB = [plane][lane][16 B]; this wave reads units rb32 = u0, u0 + 1
-  const srd_t srdW = make_srd(p.W, p.w_bytes);
+  const srd_words srdW = make_srd_words(p.W, p.w_bytes);
   const unsigned w_u0 = (unsigned)((p.w_row0 + j0 + wj0) >> 5), w_ks0 = (unsigned)(p.w_k0 >> 4);
   const unsigned voW = 16u * (unsigned)lane;
   struct BFrag { u32x4 h[2], l[2]; };
+  // The weight loads are asm statements with their completion counted by hand (wait_b below).  As builtins, hipcc's own
+  // vm-counter bookkeeping put conservative waits behind them at the loop header (s_waitcnt vmcnt(6) ahead of the first
+  // MFMA: the fragments requested ONE step earlier had to be home, i.e. the two-step prefetch was undone) and re-used the
+  // registers of the fragment set that is dead at the header as VALU temporaries, each with a WAW wait on a load.
+  // A step beyond K is rejected through the scalar offset.
   auto loadB = [&](int s, BFrag& b) {
-    const unsigned so = ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_u0) * 2048u;
-    const unsigned vo = s < nks ? voW : OOB;
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj) {
-      b.h[nj] = __builtin_amdgcn_raw_buffer_load_b128(srdW, vo == OOB ? OOB : vo + 2048u * nj, so, 0);
-      b.l[nj] = __builtin_amdgcn_raw_buffer_load_b128(srdW, vo == OOB ? OOB : vo + 2048u * nj + 1024u, so, 0);
-    }
+    const unsigned so = s < nks ? ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_u0) * 2048u : OOB;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(b.h[0]) : "v"(voW), "s"(srdW), "s"(so));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(b.l[0]) : "v"(voW), "s"(srdW), "s"(so));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:2048" : "=v"(b.h[1]) : "v"(voW), "s"(srdW), "s"(so));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:3072" : "=v"(b.l[1]) : "v"(voW), "s"(srdW), "s"(so));
+  };
+  // everything but the six youngest requests (= the next step's) has landed; names the fragments so that no use of them
+  // can be scheduled above the wait
+  auto wait_b = [&](BFrag& b) {
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(b.h[0]), "+v"(b.l[0]), "+v"(b.h[1]), "+v"(b.l[1])::"memory");
   };
 
   // ---- exponents along k: table in LDS + a bit per step where the scale changes (128 steps at most: K <= 2048).
@@ -139,11 +165,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti, sA - 1, nks1) : eA;
   const int eBp = sB < nks ? kc_exp_of_step(p, ti, sB - 1, nks1) : eB;
   const int e_last = kc_exp_of_step(p, ti, nks - 1, nks1);
-  // vm-counter order from here on: [A(0) A(1)] [W(0)] then per step s: [W(s + 1)] [A(s + 2)] -- at the top of step s the
-  // two pieces of A(s + 1) are the only requests allowed to be outstanding: s_waitcnt vmcnt(2)
-  issueA(0, 0, 0); issueA(0, 0, 1);
-  BFrag bq0, bq1;
+  // Both operands are requested TWO steps ahead.  vm-counter order: [W(0) A(0)] [W(1) A(1)], then per step s:
+  // [W(s + 2) x 4] [A(s + 2) x 2] -- at the top of step s everything of step s + 1 (six requests) may be outstanding:
+  // s_waitcnt vmcnt(6).  (One step ahead for W measured 82 us of L2 latency on the critical path of a 339 us loop.)
+  BFrag bq0, bq1, bq2;
   loadB(0, bq0);
+  issueA(0, 0, 0); issueA(0, 0, 1);
+  loadB(1, bq1);
   issueA(1, 1, 0); issueA(1, 1, 1);
   if (wave == 0) { etab[sA] = eA; etab[sB] = eB; }
   const unsigned long long chg0 = __builtin_amdgcn_ballot_w64(eA != eAp), chg1 = __builtin_amdgcn_ballot_w64(eB != eBp);
@@ -164,15 +192,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #ifdef BSP_ABL_STAMP
   unsigned long long st_wait = 0, st_vm = 0;
 #endif
-  // one k-step: MFMAs of step s on (LDS slot, weight registers `bc`); `bn` receives the weight fragments of step s + 1
-  auto step = [&](int s, int slot, const BFrag& bc, BFrag& bn) {
+  // one k-step: MFMAs of step s on (LDS slot, weight registers `bc`); `bn` receives the weight fragments of step s + 2
+  auto step = [&](int s, int slot, BFrag& bc, BFrag& bn) {
 #ifdef BSP_ABL_STAMP
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
 #if defined(BSP_ABL_NODMA) || defined(BSP_ABL_NOBLOAD)
     wait_vm<0>();
 #else
-    wait_vm<2>();
+    wait_b(bc);
 #endif
 #ifdef BSP_ABL_STAMP
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
@@ -182,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
     const unsigned long long c2 = __builtin_amdgcn_s_memtime();
     st_vm += c1 - c0; st_wait += c2 - c1;
 #endif
-    if (__builtin_expect(((s < 64 ? chg0 >> s : chg1 >> (s - 64)) & 1ull) != 0ull, 0)) {
+    if (__builtin_expect((((s & 64) ? chg1 : chg0) >> (s & 63)) & 1ull, 0)) {
       const int de = etab[s] - etab[s - 1];
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
@@ -190,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
         for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
     }
 #ifndef BSP_ABL_NOBLOAD
-    loadB(s + 1, bn);
+    loadB(s + 2, bn);
 #endif
     const char* st = lds + slot * KC_A;
     f16x8 ah[4], al[4];
@@ -233,11 +261,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   // The k-loop runs at raised priority: while the SIMD's other wave (the co-resident workgroup) is in its VALU-heavy
   // epilogue, MFMA issue goes first and the epilogue stream fills the 24 of every 32 cycles the matrix pipe leaves free.
   __builtin_amdgcn_s_setprio(2);
-  for (int s = 0; s < nks; s += 4) {
-    step(s, 0, bq0, bq1);
+  for (int s = 0; s < nks; s += 3) {
+    step(s, 0, bq0, bq2);
     if (s + 1 < nks) step(s + 1, 1, bq1, bq0);
-    if (s + 2 < nks) step(s + 2, 2, bq0, bq1);
-    if (s + 3 < nks) step(s + 3, 3, bq1, bq0);
+    if (s + 2 < nks) step(s + 2, 2, bq2, bq1);
   }
   __builtin_amdgcn_s_setprio(0);
   wait_vm<0>();        // rejected requests behind the last stage write zeros into the ring: drain before re-using it
@@ -464,7 +491,7 @@ __global__ __launch_bounds__(256, 4) void gemm_kcn_kernel(const KcArgs p) {
   const int rowl = lane & 31, kh = lane >> 5, swz = (rowl >> 2) & 3;
   const unsigned fo0 = (unsigned)rowl * 64u + (unsigned)(((0 + kh) ^ swz) << 4);
   const unsigned fo1 = (unsigned)rowl * 64u + (unsigned)(((2 + kh) ^ swz) << 4);
-  auto step = [&](int s, int slot, const BFrag& bc, BFrag& bn) {
+  auto step = [&](int s, int slot, BFrag& bc, BFrag& bn) {
     wait_vm<2>();
     barrier_raw();
     if (__builtin_expect(((s < 64 ? chg0 >> s : chg1 >> (s - 64)) & 1ull) != 0ull, 0)) acc = scale_acc(acc, etab[s] - etab[s - 1]);
@@ -529,10 +556,11 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
   float* C = p.C + (size_t)split * p.slab_stride;
 
   // ---- DMA sources: a piece is 1 KiB = one point row of the 256-column operand (eight 128-byte rows of the 32-column one)
-  const srd_t srdA = make_srd(p.A + ((size_t)kBeg * p.lda + p.a_col0 + i0) * 4,
-                              clamp_bytes(kEnd > kBeg ? ((unsigned long long)(kEnd - kBeg) * p.lda - (p.a_col0 + i0)) * 4ull : 0ull));
-  const srd_t srdB = make_srd(p.B + ((size_t)kBeg * p.ldb + p.b_col0 + j0) * 4,
-                              clamp_bytes(kEnd > kBeg ? ((unsigned long long)(kEnd - kBeg) * p.ldb - (p.b_col0 + j0)) * 4ull : 0ull));
+  const srd_words srdA = make_srd_words(p.A + ((size_t)kBeg * p.lda + p.a_col0 + i0) * 4,
+                                        clamp_bytes(kEnd > kBeg ? ((unsigned long long)(kEnd - kBeg) * p.lda - (p.a_col0 + i0)) * 4ull : 0ull));
+  const srd_words srdB = make_srd_words(p.B + ((size_t)kBeg * p.ldb + p.b_col0 + j0) * 4,
+                                        clamp_bytes(kEnd > kBeg ? ((unsigned long long)(kEnd - kBeg) * p.ldb - (p.b_col0 + j0)) * 4ull : 0ull));
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
   constexpr int PA = T::A_PITCH;
   constexpr int A_PIECES = T::A_BYTES / 1024;                         // 16 (TI = 256) or 2 (TI = 32)
   constexpr int NPA = (A_PIECES + T::WAVES - 1) / T::WAVES;           // A pieces per wave: 2 / 1 (waves >= 2 of the narrow form: a rejected one)
@@ -555,17 +583,17 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
   }
   auto issue = [&](int s, int slot) {
     const int prow0 = kBeg + 16 * s;
-    char* d = lds + slot * T::STAGE;
 #pragma unroll
     for (int q = 0; q < NPA; ++q) {
       const int piece = wave * NPA + q;
       const bool ok = s < nks && prA[q] >= 0 && prow0 + prA[q] < kEnd;
-      dma16(srdA, piece < A_PIECES ? d + piece * 1024 : lds + T::DUMMY + wave * 1024, ok ? voA[q] : OOB, (unsigned)s * 16u * (unsigned)p.lda * 4u);
+      dma16_asm(srdA, lds0 + (unsigned)(piece < A_PIECES ? slot * T::STAGE + piece * 1024 : T::DUMMY + wave * 1024), ok ? voA[q] : OOB,
+                (unsigned)s * 16u * (unsigned)p.lda * 4u);
     }
 #pragma unroll
     for (int q = 0; q < NPB; ++q) {
       const bool ok = s < nks && prow0 + prB[q] < kEnd;
-      dma16(srdB, d + T::A_BYTES + prB[q] * 1024, ok ? voB[q] : OOB, (unsigned)s * 16u * (unsigned)p.ldb * 4u);
+      dma16_asm(srdB, lds0 + (unsigned)(slot * T::STAGE + T::A_BYTES + prB[q] * 1024), ok ? voB[q] : OOB, (unsigned)s * 16u * (unsigned)p.ldb * 4u);
     }
   };
   // ---- exponent sums per 128-point chunk, per wave (its 128-row / 64-column sub-tile lies in one block of either tensor)
@@ -617,37 +645,115 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
 
   int e_cur = 0;
   constexpr int NPIECE = NPA + NPB;
-  auto step = [&](int s, int slot) {
-    wait_vm<NPIECE>();
+  // exponent bookkeeping at the start of a 128-point chunk: rescale the accumulators when the pair of exponents changes
+  auto chunk = [&](int s) {
+    if ((s & 7) != 0) return;
+    const int e_new = __builtin_amdgcn_readfirstlane(esum[wave * T::MAXCH + (s >> 3)]);
+    if (s == 0) e_cur = e_new;
+    else if (__builtin_expect(e_new != e_cur, 0)) {
+      const int de = e_new - e_cur;
+#pragma unroll
+      for (int mi = 0; mi < T::MI; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
+      e_cur = e_new;
+    }
+  };
+#ifdef BSP_DW_PINGPONG
+  if constexpr (TI == 256) {
+    // Ping-pong: the eight waves form two groups (tile rows 0-127 / 128-255; one wave of each per SIMD) that run the same
+    // two-phase step -- M: request stage s + 2, read the 24 fragments of stage s | C: 24 MFMAs on those registers -- one
+    // phase apart, with a workgroup barrier after every phase.
+    //   phase:    0      1      2      3     ...
+    //   group 0:  M(0)   C(0)   M(1)   C(1)
+    //   group 1:  -      M(0)   C(0)   M(1)
+    // Stage s + 1 is awaited (own pieces, counted vmcnt) before the barrier that ends phase 2 s + 1, one barrier ahead of
+    // its first reader (group 0, phase 2 s + 2); stage s + 2 is requested into the slot of stage s - 1 no earlier than
+    // phase 2 s, one barrier after its last reader (group 1, phase 2 s - 1).
+    const int grp = wave >> 2;
+    f16x8 fa_h[4], fa_l[4], fb_h[2], fb_l[2];
+    auto phaseM = [&](int s, int slot) {
+      issue(s + 2, (slot + 2) % 3);
+      chunk(s);
+      const char* st = lds + slot * T::STAGE;
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) { fb_h[nj] = trfrag(st, foB[nj][0], 1024); fb_l[nj] = trfrag(st, foB[nj][1], 1024); }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) { fa_h[mi] = trfrag(st, foA[mi][0], PA); fa_l[mi] = trfrag(st, foA[mi][1], PA); }
+    };
+    auto phaseC = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = mfma3(fa_h[mi], fa_l[mi], fb_h[nj], fb_l[nj], acc[mi][nj]);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    wait_vm<NPIECE>();          // stage 0 (own pieces); stage 1 stays in flight
     barrier_raw();
-    issue(s + 2, (slot + 2) % 3);
-    if ((s & 7) == 0) {     // a new 128-point chunk: its own pair of exponents
-      const int e_new = __builtin_amdgcn_readfirstlane(esum[wave * T::MAXCH + (s >> 3)]);
-      if (s == 0) e_cur = e_new;
-      else if (__builtin_expect(e_new != e_cur, 0)) {
-        const int de = e_new - e_cur;
-#pragma unroll
-        for (int mi = 0; mi < T::MI; ++mi)
-#pragma unroll
-          for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
-        e_cur = e_new;
+    if (grp == 0) {
+      int slot = 0;
+      for (int s = 0; s < nks; ++s) {
+        phaseM(s, slot);
+        barrier_raw();
+        phaseC();
+        wait_vm<NPIECE>();      // stage s + 1 landed (stage s + 2 in flight)
+        barrier_raw();
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+      barrier_raw();            // group 1's last compute phase
+    } else {
+      barrier_raw();            // group 0's first memory phase
+      int slot = 0;
+      for (int s = 0; s < nks; ++s) {
+        phaseM(s, slot);
+        wait_vm<NPIECE>();      // stage s + 1 landed (the stage s + 2 just requested stays in flight)
+        barrier_raw();
+        phaseC();
+        barrier_raw();
+        slot = slot == 2 ? 0 : slot + 1;
       }
     }
+  } else
+#endif
+  {
+  auto step = [&](int s, int slot) {
+#ifndef BSP_ABL_DW_NODMA
+    wait_vm<NPIECE>();
+#endif
+    barrier_raw();
+#ifndef BSP_ABL_DW_NODMA
+    issue(s + 2, (slot + 2) % 3);
+#endif
+    chunk(s);
     const char* st = lds + slot * T::STAGE;
     f16x8 bh[2], bl[2];
+#ifdef BSP_ABL_DW_NOLDSREAD
+    bh[0] = bh[1] = bl[0] = bl[1] = __builtin_bit_cast(f16x8, u32x4{(unsigned)s, 1u, 2u, 3u});
+#else
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) { bh[nj] = trfrag(st, foB[nj][0], 1024); bl[nj] = trfrag(st, foB[nj][1], 1024); }
+#endif
 #pragma unroll
     for (int mi = 0; mi < T::MI; ++mi) {
+#ifdef BSP_ABL_DW_NOLDSREAD
+      const f16x8 ah = bh[0], al = bl[1];
+#else
       const f16x8 ah = trfrag(st, foA[mi][0], PA), al = trfrag(st, foA[mi][1], PA);
+#endif
+#ifdef BSP_ABL_DW_NOMFMA
+      asm volatile("" ::"v"(ah), "v"(al), "v"(bh[0]), "v"(bl[0]), "v"(bh[1]), "v"(bl[1]));
+#else
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = mfma3(ah, al, bh[nj], bl[nj], acc[mi][nj]);
+#endif
     }
   };
   for (int s = 0; s < nks; s += 3) {
     step(s, 0);
     if (s + 1 < nks) step(s + 1, 1);
     if (s + 2 < nks) step(s + 2, 2);
+  }
   }
   wait_vm<0>();
   barrier_raw();

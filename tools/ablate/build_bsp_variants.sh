@@ -11,8 +11,10 @@ build() {  # name, macros...
   /opt/rocm/bin/hipcc $FLAGS "$@" -c bsp_gemm.hip -o /tmp/bsp_gemm_$name.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsnerf_hip_$name.so gemm.o gemm_x6.o /tmp/bsp_gemm_$name.o bsp_aux.o aux_kernels.o composite.o loss.o optim.o api.o
 }
-build stamp -DBSP_ABL_STAMP &
-build stamp1wg -DBSP_ABL_STAMP -DBSP_ABL_ONEWG &
-build onewg -DBSP_ABL_ONEWG &
+build o_noepi -DBSP_ABL_ONEWG -DBSP_ABL_NOEPI &
+build o_mfmaonly -DBSP_ABL_ONEWG -DBSP_ABL_NOEPI -DBSP_ABL_NOLDSREAD -DBSP_ABL_NODMA -DBSP_ABL_NOBLOAD &
+build o_nobload -DBSP_ABL_ONEWG -DBSP_ABL_NOEPI -DBSP_ABL_NOBLOAD &
+build o_nolds -DBSP_ABL_ONEWG -DBSP_ABL_NOEPI -DBSP_ABL_NOLDSREAD &
+build o_nodma -DBSP_ABL_ONEWG -DBSP_ABL_NOEPI -DBSP_ABL_NODMA &
 wait
 ls -la $OUT/*.so
