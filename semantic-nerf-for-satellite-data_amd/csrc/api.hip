@@ -12,6 +12,12 @@
 
 namespace snerf {
 
+// bsp_pass.hip: the pass sequences of the default arithmetic (block-scaled fp16-plane activations)
+int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutputs* out, void* workspace, hipStream_t st);
+int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutGrads* go, float* gp, float* d_t, float* d_t_s,
+                 void* workspace, hipStream_t st);
+void build_wjobs(const Plan& p, bsp::WPackTable& tb);
+
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -38,6 +44,106 @@ DwSplit dw_choose(int P, int rows, int cols, bool narrow_rows) {
   d.k_split = round_up((P + ns - 1) / ns, 32);
   d.ns = (P + d.k_split - 1) / d.k_split;
   return d;
+}
+
+// split-K choice for the plane dW kernel: 256 x 256 tiles, one workgroup per CU -> tiles x splits ~ 512 (two rounds),
+// splits of whole 128-point exponent blocks, at most 16384 points each
+DwSplit dw_choose_bsp(int P, int rows, int cols, bool narrow_rows) {
+  const int tiles = (narrow_rows ? 1 : (rows + 255) / 256) * ((cols + 255) / 256);
+  int ns = (512 + tiles / 2) / tiles;
+  const int ns_max = P / 1024 > 1 ? P / 1024 : 1;
+  if (ns > ns_max) ns = ns_max;
+  if (ns < 1) ns = 1;
+  DwSplit d;
+  d.k_split = round_up((P + ns - 1) / ns, 128);
+  if (d.k_split > 16384) d.k_split = 16384;
+  d.ns = (P + d.k_split - 1) / d.k_split;
+  return d;
+}
+
+// ---- block-scaled plane layout (fmt 1): weight operand packs + workspace -------------------------------------------
+static void plan_bsp(Plan& p) {
+  // weight operands: every K-contiguous GEMM's B, as a WF16 pack behind the fp32 region (csrc/bsp.h)
+  size_t off = 0;
+  int n = 0, ne = 0;
+  auto job = [&](int rows, int K, int e) {
+    p.wj_off[n] = off; p.wj_rows[n] = rows; p.wj_K[n] = K; p.wj_e[n] = e;
+    off += bsp::wp16_bytes(rows, K);
+    return n++;
+  };
+  for (int i = 0; i < p.L; ++i) {
+    const int e = ne++;
+    p.wj_tr[i] = job(p.W, p.k_tr[i], e);
+    p.wj_tt[i] = i > 0 ? job(p.W, p.W, e) : -1;
+  }
+  { const int e = ne++; p.wj_fs = job(p.W, p.W, e); p.wj_sig = job(NARROW, p.W, e); p.wj_tfs = job(p.W, p.W + NARROW, e); }
+  { const int e = ne++; p.wj_h1 = job(p.N1, p.FA, e); p.wj_th1 = job(p.FA, p.N1, e); }
+  { const int e = ne++; p.wj_s2 = job(p.H, p.H, e); p.wj_ts2 = job(p.H, p.H, e); }
+  { const int e = ne++; p.wj_s3 = job(p.H, p.H, e); p.wj_ts3 = job(p.H, p.H, e); }
+  { const int e = ne++; p.wj_s4 = job(NARROW, p.H, e); p.wj_ts4 = job(p.H, NARROW, e); }
+  { const int e = ne++; p.wj_fin = job(NARROW, p.KF, e); p.wj_tfin = job(p.KF, NARROW, e); }
+  p.n_wjobs = n;
+  p.wp_bytes = round_up_sz(off, 256);
+  p.packed_floats = p.n_fp32 + (p.wp_bytes + 2 * Plan::WJ_MAX * 4 + 256) / 4;
+
+  // workspace: activations as planes (4 bytes per element, like fp32) + exponent tables + sign words
+  size_t wo = 0;
+  auto wtake = [&](size_t bytes) { size_t o = wo; wo += round_up_sz(bytes, 256); return o; };
+  const size_t Pp = p.Pp;
+  auto planes = [&](int ld) { return wtake(bsp::plane_bytes(Pp, ld)); };
+  auto etab = [&](int ld) { return wtake(bsp::etab_ints(Pp, ld) * 4); };
+  auto signs = [&](int ld) { return wtake(bsp::sign_words(Pp, ld) * 4); };
+  const bool keep_c = p.train && p.siren;
+  p.h1w = p.sc ? p.H : p.N1;
+  p.sign_deriv = true;
+  p.o_z = wtake(((size_t)p.P + 4) * 4);
+  p.o_T = wtake((size_t)p.P * 4);
+  p.o_rgbraw = wtake((size_t)p.N * 3 * 4);
+  p.o_pe = planes(p.Ep); p.e_pe = etab(p.Ep);
+  if (p.train) {
+    for (int i = 0; i < p.L; ++i) { p.o_h[i] = planes(p.W); p.e_h[i] = etab(p.W); p.o_c[i] = keep_c ? signs(p.W) : 0; }
+  } else {
+    const size_t a = planes(p.W), b = planes(p.W), ea = etab(p.W), eb = etab(p.W);
+    for (int i = 0; i < p.L; ++i) { p.o_h[i] = (i & 1) ? b : a; p.e_h[i] = (i & 1) ? eb : ea; p.o_c[i] = 0; }
+  }
+  p.o_fa = planes(p.FA); p.e_fa = etab(p.FA);
+  p.o_h1 = planes(p.h1w); p.e_h1 = etab(p.h1w); p.o_c1 = keep_c ? signs(p.h1w) : 0;
+  p.o_s2 = planes(p.H); p.e_s2 = etab(p.H); p.o_cs2 = keep_c ? signs(p.H) : 0;
+  p.o_s3 = planes(p.H); p.e_s3 = etab(p.H); p.o_cs3 = keep_c ? signs(p.H) : 0;
+  p.o_sigo = wtake(Pp * NARROW * 4); p.o_fino = wtake(Pp * NARROW * 4); p.o_suno = wtake(Pp * NARROW * 4);
+  p.maxw = p.W > p.FA ? p.W : p.FA;
+  if (p.h1w > p.maxw) p.maxw = p.h1w;
+  p.nrb = (p.P + 31) / 32;
+  p.comp_blocks = composite_bwd_blocks(p.N);
+  if (p.train) {
+    p.o_dza = planes(p.maxw); p.e_dza = etab(p.maxw);
+    p.o_dzb = planes(p.maxw); p.e_dzb = etab(p.maxw);
+    p.o_dsa = planes(p.H); p.e_dsa = etab(p.H);
+    p.o_dsb = planes(p.H); p.e_dsb = etab(p.H);
+    p.o_dsig = wtake(Pp * NARROW * 4); p.o_dfin = wtake(Pp * NARROW * 4); p.o_dsun = wtake(Pp * NARROW * 4);
+    p.o_pdsig = planes(NARROW); p.e_dsig = etab(NARROW);
+    p.o_pdfin = planes(NARROW); p.e_dfin = etab(NARROW);
+    p.o_pdsun = planes(NARROW); p.e_dsun = etab(NARROW);
+    p.o_colsum = wtake((size_t)p.nrb * p.maxw * 4);
+    p.o_colsum2 = wtake((size_t)64 * (p.maxw > p.sky_floats ? p.maxw : p.sky_floats) * 4);
+    auto need = [&](int rows, int ld, int cols, bool narrow) {
+      const DwSplit d = dw_choose_bsp(p.P, rows, cols, narrow);
+      return round_up_sz((size_t)rows * ld, 64) * d.ns;
+    };
+    size_t cap = need(p.h1w, p.FA, p.FA, false);
+    for (int i = 0; i < p.L; ++i) { const size_t c = need(p.W, p.k_tr[i], p.W, false); if (c > cap) cap = c; }
+    size_t c2 = need(p.W + NARROW, p.W, p.W, false); if (c2 > cap) cap = c2;
+    c2 = need(NARROW, p.KF, p.KF, true); if (c2 > cap) cap = c2;
+    c2 = need(NARROW, p.H, p.H, true); if (c2 > cap) cap = c2;
+    c2 = need(p.H, p.H, p.H, false); if (c2 > cap) cap = c2;
+    p.slab_floats = cap;
+    p.o_slab = wtake(p.slab_floats * 4);
+    { size_t big = (size_t)p.N1 * p.FA; for (int i = 0; i < p.L; ++i) if ((size_t)p.W * p.k_tr[i] > big) big = (size_t)p.W * p.k_tr[i];
+      if ((size_t)(p.W + NARROW) * p.W > big) big = (size_t)(p.W + NARROW) * p.W; if ((size_t)NARROW * p.KF > big) big = (size_t)NARROW * p.KF;
+      p.o_slab2 = wtake(64 * round_up_sz(big, 64) * 4); }
+    p.o_skyslab = wtake((size_t)p.comp_blocks * 4 * p.sky_floats * 4);
+  }
+  p.ws_bytes = wo;
 }
 
 int make_plan(const SnerfDesc* d, Plan* pl) {
@@ -78,7 +184,9 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.sbeta_ts = sbeta && sep_ts;
   p.x_sun = 0; p.x_t = 3; p.x_ts = sep_ts ? 3 + p.tau : -1;
   p.Xp = round_up(3 + p.tau + (sep_ts ? p.tau : 0), 16);  // FA % 16 == 0: weight planes are stored in 16-k tiles
-  p.FA = p.W + p.Xp;
+  if (p.fmt == 1 && ((p.H & 15) || p.Xp != 16)) return bad("the default arithmetic needs feat_last % 16 == 0 and 3 + t_dim (x2 with separate t_s) <= 16; use SNERF_FLAG_SPLIT3");
+  p.Wf = p.fmt == 1 ? round_up(p.W, 128) : p.W;         // extras block on an exponent-block boundary
+  p.FA = p.Wf + p.Xp;
   int nb = 0;
   p.blk_rgb = nb++;
   p.blk_sem = sem ? nb++ : -1;
@@ -86,8 +194,10 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.blk_sbeta = sbeta ? nb++ : -1;
   p.blk_sun = nb++;
   p.nblk = nb;
-  p.N1 = nb * p.H;
   p.KF = (nb - 1) * p.H;
+  if (p.fmt == 1) p.KF = round_up(p.KF, 128);           // sun block on an exponent-block boundary (pad rows / columns are zero)
+  p.sun_col = p.KF;
+  p.N1 = p.KF + p.H;
 
   size_t off = 0;
   auto take = [&](size_t n) { size_t o = off; off += round_up_sz(n, 64); return o; };
@@ -179,6 +289,7 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
     p.o_skyslab = wtake((size_t)p.comp_blocks * 4 * p.sky_floats);
   }
   p.ws_bytes = wo;
+  if (p.fmt == 1) plan_bsp(p);
   return SNERF_OK;
 }
 
@@ -218,10 +329,11 @@ static void build_tables(const Plan& p, const SnerfParams* w, TableBuilder& tb) 
   tb.add(w->sigma_b, 1, 1, 1, p.b_fs + W, 1);
   auto head1 = [&](int blk, float* w0, float* b0, int extra, int xcol) {
     const int in = W + extra;
-    const size_t row0 = p.w_h1 + (size_t)blk * H * p.FA;
+    const size_t r0 = blk == p.blk_sun ? (size_t)p.sun_col : (size_t)blk * H;
+    const size_t row0 = p.w_h1 + r0 * p.FA;
     tb.add(w0, in, H, W, row0, p.FA);
-    if (extra > 0) tb.add(w0 ? w0 + W : nullptr, in, H, extra, row0 + W + xcol, p.FA);
-    tb.add(b0, H, 1, H, p.b_h1 + (size_t)blk * H, H);
+    if (extra > 0) tb.add(w0 ? w0 + W : nullptr, in, H, extra, row0 + p.Wf + xcol, p.FA);
+    tb.add(b0, H, 1, H, p.b_h1 + r0, H);
   };
   head1(p.blk_rgb, w->rgb_w0, w->rgb_b0, p.rgb_t ? p.tau : 0, p.x_t);
   if (p.blk_sem >= 0) head1(p.blk_sem, w->sem_w0, w->sem_b0, (p.sem_t || p.sem_ts) ? p.tau : 0, p.sem_ts ? p.x_ts : p.x_t);
@@ -292,7 +404,7 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
   ea.sun_d = in->sun_d; ea.sun_stride = in->sun_stride; ea.t = in->t; ea.t_s = in->t_s;
   ea.dir_is_sun = (p.sc && !in->xyz) ? 1 : 0;
   ea.N = p.N; ea.S = p.S; ea.F = p.F; ea.Ep = p.Ep; ea.pe = ws.f(p.o_pe);
-  ea.fa = ws.f(p.o_fa); ea.FA = p.FA; ea.W = W; ea.Xp = p.Xp; ea.x_sun = p.x_sun; ea.x_t = p.x_t; ea.x_ts = p.x_ts; ea.tau = p.tau;
+  ea.fa = ws.f(p.o_fa); ea.FA = p.FA; ea.W = p.Wf; ea.Xp = p.Xp; ea.x_sun = p.x_sun; ea.x_t = p.x_t; ea.x_ts = p.x_ts; ea.tau = p.tau;
   RC(launch_encode(ea, st));
   if (p.fmt == 1) {  // operand maxima of the tensors the encode kernel wrote (GEMM epilogues add their own)
     SNERF_HIP_CHECK(hipMemsetAsync(ws.u(p.o_amax), 0, (size_t)p.n_fwd_slots * 64 * sizeof(unsigned), st));
@@ -333,14 +445,14 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
   {  // first layer of every head in one GEMM (sc pass: sun-visibility block only)
     GemmArgs g;
     g.A = ws.f(p.o_fa); g.lda = p.FA; g.I = P; g.K = p.FA;
-    const size_t r0 = p.sc ? (size_t)p.blk_sun * H : 0;
+    const size_t r0 = p.sc ? (size_t)p.sun_col : 0;
     weights(g, p, pk, p.w_h1, p.N1, p.FA, (int)r0); g.J = p.h1w;
     g.C = ws.f(p.o_h1); g.ldc = p.h1w; g.bias = pk + p.b_h1 + r0; g.act = act; g.w0 = 1.f;
     g.a_max = slot(p, ws, p.s_fa); g.c_max = slot(p, ws, p.s_h1);
     if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_c1); else g.C2 = ws.f(p.o_c1); }
     RC(launch_gemm(g, st));
   }
-  const int sun_col = p.sc ? 0 : p.blk_sun * H;
+  const int sun_col = p.sc ? 0 : p.sun_col;
   {  // sun visibility layers 2,3 (rs_semantic.py:217-227)
     GemmArgs g;
     g.A = ws.f(p.o_h1) + sun_col; g.lda = p.h1w; weights(g, p, pk, p.w_s2, H, H); g.I = P; g.J = H; g.K = H;
@@ -450,7 +562,7 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
                        gp + p.sky, st));
 
   float* dz1 = ws.f(p.o_dza);  // d(pre-activation) of the fused first head layer, [P][h1w]
-  const int sun_col = p.sc ? 0 : p.blk_sun * H;
+  const int sun_col = p.sc ? 0 : p.sun_col;
   if (!p.sc) {
     // 1. final head layers
     const DwMat mf = dw_begin(p, NARROW, p.KF, p.KF, true);
@@ -491,11 +603,11 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     g.C = dz1 + sun_col; g.ldc = p.h1w; dact(g, p.o_c1, p.o_h1, p.h1w, sun_col);
     g.a_max = slot(p, ws, p.s_dsb); g.c_max = slot(p, ws, p.s_dz1);
     RC(launch_gemm(g, st));  // dz1[:, sun block]
-    RC(bias_from_colsum(p, ws, H, gp + p.b_h1 + (size_t)p.blk_sun * H, st));
+    RC(bias_from_colsum(p, ws, H, gp + p.b_h1 + (size_t)p.sun_col, st));
   }
   float* dfa = ws.f(p.o_dzb);  // [P][FA]
   {  // 3. fused first head layer: dW, then d[feats | extras]
-    const size_t r0 = p.sc ? (size_t)p.blk_sun * H : 0;
+    const size_t r0 = p.sc ? (size_t)p.sun_col : 0;
     const DwMat m1 = dw_begin(p, p.h1w, p.FA, p.FA, false);
     RC(dw_gemm(p, ws, m1, dz1, p.h1w, p.h1w, false, ws.f(p.o_fa), p.FA, p.FA, 0, st, p.s_dz1, p.s_fa));
     RC(dw_reduce(p, ws, m1, (size_t)p.h1w * p.FA, gp + p.w_h1 + r0 * p.FA, st));
@@ -506,8 +618,8 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;  // columns [0,W) = bias grad of feats_from_xyz
     RC(launch_gemm(g, st));
     RC(bias_from_colsum(p, ws, W, gp + p.b_fs, st));
-    if (d_t) RC(launch_ray_sum(dfa, p.FA, W + p.x_t, p.N, p.S, p.tau, d_t, st));
-    if (d_t_s && p.x_ts >= 0) RC(launch_ray_sum(dfa, p.FA, W + p.x_ts, p.N, p.S, p.tau, d_t_s, st));
+    if (d_t) RC(launch_ray_sum(dfa, p.FA, p.Wf + p.x_t, p.N, p.S, p.tau, d_t, st));
+    if (d_t_s && p.x_ts >= 0) RC(launch_ray_sum(dfa, p.FA, p.Wf + p.x_ts, p.N, p.S, p.tau, d_t_s, st));
   }
   float* dz = ws.f(p.o_dza);  // dz1 is dead from here on
   {  // 4. feats + sigma: dW for the [W + NARROW][W] matrix, then dz of the last trunk layer
@@ -606,6 +718,15 @@ int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* p
   hipStream_t st = (hipStream_t)stream;
   SNERF_HIP_CHECK(hipMemsetAsync(packed, 0, p.n_fp32 * sizeof(float), st));
   for (int i = 0; i < tb.nt; ++i) RC(launch_copy_table(tb.tabs[i], packed, 0, st));
+  if (p.fmt == 1) {
+    // default arithmetic: every weight operand (matrix or its transpose) as a fragment-ordered fp16-plane pack with one
+    // exponent per matrix -- two launches over a job table (|max| pass, pack pass)
+    bsp::WPackTable wt;
+    build_wjobs(p, wt);
+    char* planes = reinterpret_cast<char*>(packed + p.n_fp32);
+    int* exps = reinterpret_cast<int*>(planes + p.wp_bytes);
+    return bsp::launch_wpack(wt, packed, planes, exps, reinterpret_cast<unsigned*>(exps + Plan::WJ_MAX), st);
+  }
   // K-contiguous transposes consumed by the dX GEMMs
   for (int i = 1; i < p.L; ++i) {
     const int hoff = ((p.skip_mask >> i) & 1u) ? p.Ep : 0;
@@ -657,6 +778,7 @@ int snerf_forward(const SnerfDesc* desc, const float* packed_params, const Snerf
   if (workspace_bytes < p.ws_bytes) { set_error("snerf_forward: workspace too small (%zu < %zu)", workspace_bytes, p.ws_bytes); return SNERF_ERR_WORKSPACE; }
   if (((uintptr_t)workspace & 255) || ((uintptr_t)packed_params & 255)) { set_error("workspace and packed params must be 256-byte aligned"); return SNERF_ERR_WORKSPACE; }
   RC(check_inputs(p, in));
+  if (p.fmt == 1) return forward_bsp(p, packed_params, in, out, workspace, (hipStream_t)stream);
   WS ws{(char*)workspace};
   return forward_impl(p, packed_params, in, out, ws, (hipStream_t)stream);
 }
@@ -670,6 +792,7 @@ int snerf_backward(const SnerfDesc* desc, const float* packed_params, const Sner
   if (workspace_bytes < p.ws_bytes) { set_error("snerf_backward: workspace too small (%zu < %zu)", workspace_bytes, p.ws_bytes); return SNERF_ERR_WORKSPACE; }
   if (((uintptr_t)workspace & 255) || ((uintptr_t)packed_params & 255) || ((uintptr_t)packed_grads & 255)) { set_error("workspace and packed buffers must be 256-byte aligned"); return SNERF_ERR_WORKSPACE; }
   RC(check_inputs(p, in));
+  if (p.fmt == 1) return backward_bsp(p, packed_params, in, gout, packed_grads, d_t, d_t_s, workspace, (hipStream_t)stream);
   WS ws{(char*)workspace};
   if ((desc->flags & SNERF_FLAG_BWD_BF16X3) && p.x6 && p.fmt == 0 && p.planes == 3) p.planes = 2;  // same Plan, fewer products in backward
   return backward_impl(p, packed_params, in, gout, packed_grads, d_t, d_t_s, ws, (hipStream_t)stream);

@@ -1,0 +1,311 @@
+// Forward / backward launch sequences of one rendering pass in the default arithmetic: every activation tensor lives
+// as block-scaled fp16 planes (bsp.h), every dense layer is one launch of bsp_gemm.hip, weights come pre-packed in
+// fragment order.  Same math, same order of layers and the same workspace roles as the fp32-storage sequences in
+// api.hip (which serve the other arithmetic modes); reference: semantic/models/rs_semantic.py:260-340 (forward),
+// its autograd backward.
+#include "aux_kernels.h"
+#include "bsp.h"
+#include "composite.h"
+#include "plan.h"
+
+namespace snerf {
+
+#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
+
+namespace {
+struct Ws {
+  char* base;
+  char* c(size_t off) const { return base + off; }
+  float* f(size_t off) const { return reinterpret_cast<float*>(base + off); }
+  int* i(size_t off) const { return reinterpret_cast<int*>(base + off); }
+  unsigned* u(size_t off) const { return reinterpret_cast<unsigned*>(base + off); }
+};
+// weight operand `job` of the packed buffer (rows [row0, ..), k >= k0 of it)
+void weights(bsp::KcArgs& g, const Plan& p, const float* pk, int job, int row0 = 0, int k0 = 0) {
+  const char* planes = reinterpret_cast<const char*>(pk + p.n_fp32);
+  g.W = planes + p.wj_off[job];
+  g.EW = reinterpret_cast<const int*>(planes + p.wp_bytes) + p.wj_e[job];
+  g.w_rb32 = (p.wj_rows[job] + 31) / 32;
+  g.w_bytes = (unsigned)bsp::wp16_bytes(p.wj_rows[job], p.wj_K[job]);
+  g.w_row0 = row0; g.w_k0 = k0;
+}
+}  // namespace
+
+int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutputs* out, void* workspace, hipStream_t st) {
+  const Ws ws{(char*)workspace};
+  const int P = p.P, W = p.W, H = p.H;
+  float* z = ws.f(p.o_z);
+  // 1. depths
+  if (in->z_vals) SNERF_HIP_CHECK(hipMemcpyAsync(z, in->z_vals, sizeof(float) * P, hipMemcpyDeviceToDevice, st));
+  else RC(launch_sample_z(in->rays, in->z_steps, in->u, z, p.N, p.S, st));
+  if (out->z_vals) SNERF_HIP_CHECK(hipMemcpyAsync(out->z_vals, z, sizeof(float) * P, hipMemcpyDeviceToDevice, st));
+  // 2. positions + encoding + extras, written as planes with their block exponents
+  EncodeArgs ea;
+  ea.rays = in->xyz ? nullptr : in->rays; ea.xyz = in->xyz; ea.z = z;
+  ea.sun_d = in->sun_d; ea.sun_stride = in->sun_stride; ea.t = in->t; ea.t_s = in->t_s;
+  ea.dir_is_sun = (p.sc && !in->xyz) ? 1 : 0;
+  ea.N = p.N; ea.S = p.S; ea.F = p.F; ea.Ep = p.Ep;
+  ea.FA = p.FA; ea.W = p.Wf; ea.Xp = p.Xp; ea.x_sun = p.x_sun; ea.x_t = p.x_t; ea.x_ts = p.x_ts; ea.tau = p.tau;
+  RC(bsp::launch_encode_bsp(ea, ws.c(p.o_pe), ws.i(p.e_pe), ws.c(p.o_fa), ws.i(p.e_fa), p.Wf, st));
+  if (p.Wf > W)   // pad columns between feats and extras (narrow test networks only): zero planes, read against zero weights
+    SNERF_HIP_CHECK(hipMemset2DAsync(ws.c(p.o_fa) + (size_t)W * 4, (size_t)p.FA * 4, 0, (size_t)(p.Wf - W) * 4, P, st));
+  // 3. trunk (rs_semantic.py:325-334)
+  const int act = p.siren ? ACT_SIN : ACT_RELU;
+  for (int i = 0; i < p.L; ++i) {
+    bsp::KcArgs g;
+    const bool skip = (p.skip_mask >> i) & 1u;
+    if (i == 0) { g.A = ws.c(p.o_pe); g.EA = ws.i(p.e_pe); g.lda = p.Ep; g.Ka = p.Ep; }
+    else if (skip) { g.A = ws.c(p.o_pe); g.EA = ws.i(p.e_pe); g.lda = p.Ep; g.Ka = p.Ep;
+                     g.A2 = ws.c(p.o_h[i - 1]); g.EA2 = ws.i(p.e_h[i - 1]); g.lda2 = W; }
+    else { g.A = ws.c(p.o_h[i - 1]); g.EA = ws.i(p.e_h[i - 1]); g.lda = W; g.Ka = W; }
+    weights(g, p, pk, p.wj_tr[i]);
+    g.I = P; g.J = W; g.K = p.k_tr[i];
+    g.C = ws.c(p.o_h[i]); g.EC = ws.i(p.e_h[i]); g.ldc = W;
+    g.bias = pk + p.b_tr[i]; g.act = act; g.w0 = (p.siren && i == 0) ? 30.f : 1.f;
+    if (p.train && p.siren) g.Csign = ws.u(p.o_c[i]);
+    RC(bsp::launch_kc(g, st));
+  }
+  const char* hl = ws.c(p.o_h[p.L - 1]); const int* ehl = ws.i(p.e_h[p.L - 1]);
+  {  // sigma pre-activation (rs_semantic.py:337) -> 32-wide fp32 buffer, column 0
+    bsp::KcArgs g;
+    g.A = hl; g.EA = ehl; g.lda = W; g.Ka = W; weights(g, p, pk, p.wj_sig);
+    g.I = P; g.J = NARROW; g.K = W; g.Cf = ws.f(p.o_sigo); g.bias = pk + p.b_fs + W;
+    RC(bsp::launch_kc_narrow(g, st));
+  }
+  {  // feats (rs_semantic.py:338), written into the first W columns of the [feats | sun | t | t_s] tensor
+    bsp::KcArgs g;
+    g.A = hl; g.EA = ehl; g.lda = W; g.Ka = W; weights(g, p, pk, p.wj_fs);
+    g.I = P; g.J = W; g.K = W; g.C = ws.c(p.o_fa); g.EC = ws.i(p.e_fa); g.ldc = p.FA; g.bias = pk + p.b_fs;
+    RC(bsp::launch_kc(g, st));
+  }
+  const int r0 = p.sc ? p.sun_col : 0;
+  {  // first layer of every head in one GEMM (sc pass: sun-visibility block only)
+    bsp::KcArgs g;
+    g.A = ws.c(p.o_fa); g.EA = ws.i(p.e_fa); g.lda = p.FA; g.Ka = p.FA; weights(g, p, pk, p.wj_h1, r0);
+    g.I = P; g.J = p.h1w; g.K = p.FA; g.C = ws.c(p.o_h1); g.EC = ws.i(p.e_h1); g.ldc = p.h1w;
+    g.bias = pk + p.b_h1 + r0; g.act = act; g.w0 = 1.f;
+    if (p.train && p.siren) g.Csign = ws.u(p.o_c1);
+    RC(bsp::launch_kc(g, st));
+  }
+  const int sun_col = p.sc ? 0 : p.sun_col;
+  {  // sun visibility layers 2, 3 (rs_semantic.py:217-227)
+    bsp::KcArgs g;
+    g.A = ws.c(p.o_h1); g.EA = ws.i(p.e_h1); g.lda = p.h1w; g.a_col0 = sun_col; g.Ka = H; weights(g, p, pk, p.wj_s2);
+    g.I = P; g.J = H; g.K = H; g.C = ws.c(p.o_s2); g.EC = ws.i(p.e_s2); g.ldc = H; g.bias = pk + p.b_s2; g.act = act;
+    if (p.train && p.siren) g.Csign = ws.u(p.o_cs2);
+    RC(bsp::launch_kc(g, st));
+    g.A = ws.c(p.o_s2); g.EA = ws.i(p.e_s2); g.lda = H; g.a_col0 = 0; weights(g, p, pk, p.wj_s3);
+    g.C = ws.c(p.o_s3); g.EC = ws.i(p.e_s3); g.bias = pk + p.b_s3;
+    if (p.train && p.siren) g.Csign = ws.u(p.o_cs3);
+    RC(bsp::launch_kc(g, st));
+  }
+  {  // sun visibility output pre-activation
+    bsp::KcArgs g;
+    g.A = ws.c(p.o_s3); g.EA = ws.i(p.e_s3); g.lda = H; g.Ka = H; weights(g, p, pk, p.wj_s4);
+    g.I = P; g.J = NARROW; g.K = H; g.Cf = ws.f(p.o_suno); g.bias = pk + p.b_s4;
+    RC(bsp::launch_kc_narrow(g, st));
+  }
+  if (!p.sc) {  // last layer of rgb / beta / beta_s / semantic heads: block-diagonal [32][KF]
+    bsp::KcArgs g;
+    g.A = ws.c(p.o_h1); g.EA = ws.i(p.e_h1); g.lda = p.h1w; g.Ka = p.KF; weights(g, p, pk, p.wj_fin);
+    g.I = P; g.J = NARROW; g.K = p.KF; g.Cf = ws.f(p.o_fino); g.bias = pk + p.b_fin;
+    RC(bsp::launch_kc_narrow(g, st));
+  }
+  // 4. composite (reads the three 32-wide fp32 buffers)
+  CompArgs c;
+  c.N = p.N; c.S = p.S; c.H = H; c.C = p.C; c.sc = p.sc; c.sem_sigmoid = p.sem_sigmoid; c.has_sbeta = p.blk_sbeta >= 0;
+  c.z = z; c.sigo = ws.f(p.o_sigo); c.fino = ws.f(p.o_fino); c.suno = ws.f(p.o_suno);
+  c.sun_d = in->sun_d; c.sun_stride = in->sun_stride; c.sky = pk + p.sky;
+  c.o_rgb = out->rgb; c.o_depth = out->depth; c.o_weights = out->weights; c.o_transparency = out->transparency;
+  c.o_albedo = out->albedo; c.o_sun = out->sun; c.o_sky = out->sky; c.o_beta = out->beta; c.o_sigmas = out->sigmas;
+  c.o_beta_s = out->beta_semantic; c.o_logits = out->semantic_logits; c.o_label = (long long*)out->semantic_label;
+  if (p.train) { c.save_T = ws.f(p.o_T); c.save_rgbraw = ws.f(p.o_rgbraw); }
+  RC(launch_composite_fwd(c, st));
+  return SNERF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct DwMat { DwSplit sp; size_t stride; int ldw; };
+DwMat dw_begin(const Plan& p, int rows, int ldw, int cols, bool narrow_rows) {
+  DwMat m;
+  m.sp = dw_choose_bsp(p.P, rows, cols, narrow_rows);
+  m.stride = round_up_sz((size_t)rows * ldw, 64);
+  m.ldw = ldw;
+  return m;
+}
+// slab[split][i][slab_off + j] = sum_p dZ[p][dz_col0 + i] X[p][x_col0 + j]
+int dw_gemm(const Plan& p, const Ws& ws, const DwMat& m, const char* dz, const int* edz, int lddz, int dz_col0, int I, bool narrow_i,
+            const char* X, const int* ex, int ldx, int x_col0, int J, size_t slab_off, hipStream_t st) {
+  bsp::DwArgs g;
+  g.A = dz; g.EA = edz; g.lda = lddz; g.a_col0 = dz_col0;
+  g.B = X; g.EB = ex; g.ldb = ldx; g.b_col0 = x_col0;
+  g.I = I; g.J = J; g.P = p.P;
+  g.C = ws.f(p.o_slab) + slab_off; g.ldc = m.ldw;
+  g.k_split = m.sp.k_split; g.n_split = m.sp.ns; g.slab_stride = m.stride;
+  return bsp::launch_dw(g, narrow_i, st);
+}
+int dw_reduce(const Plan& p, const Ws& ws, const DwMat& m, size_t count, float* gout, hipStream_t st) {
+  return reduce_partials(ws.f(p.o_slab), m.sp.ns, m.stride, (int)count, ws.f(p.o_slab2), gout, st);
+}
+int bias_from_colsum(const Plan& p, const Ws& ws, int width, float* gout, hipStream_t st) {
+  return reduce_partials(ws.f(p.o_colsum), p.nrb, (size_t)p.maxw, width, ws.f(p.o_colsum2), gout, st);
+}
+// bias gradient of a 32-wide pre-activation gradient; the same pass writes its planes + exponents (the dX / dW operands)
+int narrow_grad(const Plan& p, const Ws& ws, const float* dnar, char* planes, int* E, float* gout, hipStream_t st) {
+  const int nb = (p.P + 255) / 256;
+  RC(bsp::launch_colsum32_bsp(dnar, p.P, ws.f(p.o_colsum), planes, E, st));
+  return reduce_partials(ws.f(p.o_colsum), nb, NARROW, NARROW, ws.f(p.o_colsum2), gout, st);
+}
+}  // namespace
+
+int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutGrads* go, float* gp, float* d_t, float* d_t_s,
+                 void* workspace, hipStream_t st) {
+  const Ws ws{(char*)workspace};
+  const int P = p.P, W = p.W, H = p.H;
+  // activation derivative in a dX epilogue, rebuilt from the stored activation h (planes o_h / exponents e_h, leading
+  // dimension ld, column col0): siren w0 * sign(cos) * sqrt(1 - h^2) with the sign words o_c; relu: h > 0
+  auto dact = [&](bsp::KcArgs& g, size_t o_c, size_t o_h, size_t e_h, int ld, int col0 = 0, float w0 = 1.f) {
+    g.H = ws.c(o_h); g.EH = ws.i(e_h); g.ldh = ld; g.h_col0 = col0;
+    if (p.siren) { g.aux_mode = AUX_SINREC; g.Hsign = ws.u(o_c); g.w0 = w0; }
+    else g.aux_mode = AUX_RELU_MASK;
+    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
+  };
+  float* dsig = ws.f(p.o_dsig); float* dfin = ws.f(p.o_dfin); float* dsun = ws.f(p.o_dsun);
+  // 0. composite backward -> gradients of the 32-wide pre-activations (+ sky MLP grads)
+  CompBwdArgs b;
+  CompArgs& c = b.f;
+  c.N = p.N; c.S = p.S; c.H = H; c.C = p.C; c.sc = p.sc; c.sem_sigmoid = p.sem_sigmoid; c.has_sbeta = p.blk_sbeta >= 0;
+  c.z = ws.f(p.o_z); c.sigo = ws.f(p.o_sigo); c.fino = ws.f(p.o_fino); c.suno = ws.f(p.o_suno);
+  c.sun_d = in->sun_d; c.sun_stride = in->sun_stride; c.sky = pk + p.sky;
+  b.T = ws.f(p.o_T); b.rgbraw = ws.f(p.o_rgbraw);
+  b.g_rgb = go->rgb; b.g_depth = go->depth; b.g_weights = go->weights; b.g_transparency = go->transparency;
+  b.g_albedo = go->albedo; b.g_sun = go->sun; b.g_sky = go->sky; b.g_beta = go->beta; b.g_sigmas = go->sigmas;
+  b.g_beta_s = go->beta_semantic; b.g_logits = go->semantic_logits;
+  b.d_sigo = dsig; b.d_fino = dfin; b.d_suno = dsun; b.sky_slab = p.sc ? nullptr : ws.f(p.o_skyslab);
+  RC(launch_composite_bwd(b, st));
+  if (!p.sc)
+    RC(reduce_partials(ws.f(p.o_skyslab), p.comp_blocks * 4, (size_t)p.sky_floats, p.sky_floats, ws.f(p.o_colsum2), gp + p.sky, st));
+
+  char* dz1 = ws.c(p.o_dza); int* edz1 = ws.i(p.e_dza);   // d(pre-activation) of the fused first head layer, [P][h1w]
+  const int sun_col = p.sc ? 0 : p.sun_col;
+  if (!p.sc) {
+    // 1. final head layers: bias gradient + planes of dfin, dW, then dz1[:, :KF] = (dfin . W_fin) * act'
+    RC(narrow_grad(p, ws, dfin, ws.c(p.o_pdfin), ws.i(p.e_dfin), gp + p.b_fin, st));
+    const DwMat mf = dw_begin(p, NARROW, p.KF, p.KF, true);
+    RC(dw_gemm(p, ws, mf, ws.c(p.o_pdfin), ws.i(p.e_dfin), NARROW, 0, NARROW, true, ws.c(p.o_h1), ws.i(p.e_h1), p.h1w, 0, p.KF, 0, st));
+    RC(dw_reduce(p, ws, mf, (size_t)NARROW * p.KF, gp + p.w_fin, st));
+    bsp::KcArgs g;
+    g.A = ws.c(p.o_pdfin); g.EA = ws.i(p.e_dfin); g.lda = NARROW; g.Ka = NARROW; weights(g, p, pk, p.wj_tfin);
+    g.I = P; g.J = p.KF; g.K = NARROW; g.C = dz1; g.EC = edz1; g.ldc = p.h1w;
+    dact(g, p.o_c1, p.o_h1, p.e_h1, p.h1w);
+    RC(bsp::launch_kc(g, st));
+    RC(bias_from_colsum(p, ws, p.KF, gp + p.b_h1, st));
+  }
+  {  // 2. sun visibility chain: output layer, layer 3, layer 2
+    RC(narrow_grad(p, ws, dsun, ws.c(p.o_pdsun), ws.i(p.e_dsun), gp + p.b_s4, st));
+    const DwMat m4 = dw_begin(p, NARROW, H, H, true);
+    const DwMat mh = dw_begin(p, H, H, H, false);
+    RC(dw_gemm(p, ws, m4, ws.c(p.o_pdsun), ws.i(p.e_dsun), NARROW, 0, NARROW, true, ws.c(p.o_s3), ws.i(p.e_s3), H, 0, H, 0, st));
+    RC(dw_reduce(p, ws, m4, (size_t)NARROW * H, gp + p.w_s4, st));
+    bsp::KcArgs g;
+    g.A = ws.c(p.o_pdsun); g.EA = ws.i(p.e_dsun); g.lda = NARROW; g.Ka = NARROW; weights(g, p, pk, p.wj_ts4);
+    g.I = P; g.J = H; g.K = NARROW; g.C = ws.c(p.o_dsa); g.EC = ws.i(p.e_dsa); g.ldc = H;
+    dact(g, p.o_cs3, p.o_s3, p.e_s3, H);
+    RC(bsp::launch_kc(g, st));  // dz_s3
+    RC(bias_from_colsum(p, ws, H, gp + p.b_s3, st));
+    RC(dw_gemm(p, ws, mh, ws.c(p.o_dsa), ws.i(p.e_dsa), H, 0, H, false, ws.c(p.o_s2), ws.i(p.e_s2), H, 0, H, 0, st));
+    RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s3, st));
+    g.A = ws.c(p.o_dsa); g.EA = ws.i(p.e_dsa); g.lda = H; g.Ka = H; g.K = H; weights(g, p, pk, p.wj_ts3);
+    g.C = ws.c(p.o_dsb); g.EC = ws.i(p.e_dsb);
+    dact(g, p.o_cs2, p.o_s2, p.e_s2, H);
+    RC(bsp::launch_kc(g, st));  // dz_s2
+    RC(bias_from_colsum(p, ws, H, gp + p.b_s2, st));
+    RC(dw_gemm(p, ws, mh, ws.c(p.o_dsb), ws.i(p.e_dsb), H, 0, H, false, ws.c(p.o_h1), ws.i(p.e_h1), p.h1w, sun_col, H, 0, st));
+    RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s2, st));
+    g.A = ws.c(p.o_dsb); g.EA = ws.i(p.e_dsb); weights(g, p, pk, p.wj_ts2);
+    g.C = dz1; g.EC = edz1; g.ldc = p.h1w; g.c_col0 = sun_col;
+    dact(g, p.o_c1, p.o_h1, p.e_h1, p.h1w, sun_col);
+    RC(bsp::launch_kc(g, st));  // dz1[:, sun block]
+    RC(bias_from_colsum(p, ws, H, gp + p.b_h1 + (size_t)p.sun_col, st));
+  }
+  char* dfa = ws.c(p.o_dzb); int* edfa = ws.i(p.e_dzb);   // [P][FA]
+  {  // 3. fused first head layer: dW, then d[feats | extras]
+    const int r0 = p.sc ? p.sun_col : 0;
+    const DwMat m1 = dw_begin(p, p.h1w, p.FA, p.FA, false);
+    RC(dw_gemm(p, ws, m1, dz1, edz1, p.h1w, 0, p.h1w, false, ws.c(p.o_fa), ws.i(p.e_fa), p.FA, 0, p.FA, 0, st));
+    RC(dw_reduce(p, ws, m1, (size_t)p.h1w * p.FA, gp + p.w_h1 + (size_t)r0 * p.FA, st));
+    bsp::KcArgs g;
+    g.A = dz1; g.EA = edz1; g.lda = p.h1w; g.Ka = p.h1w; weights(g, p, pk, p.wj_th1, 0, r0);
+    g.I = P; g.J = p.FA; g.K = p.h1w; g.C = dfa; g.EC = edfa; g.ldc = p.FA;
+    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;   // columns [0, W) = bias gradient of feats_from_xyz
+    RC(bsp::launch_kc(g, st));
+    RC(bias_from_colsum(p, ws, W, gp + p.b_fs, st));
+    if (d_t) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_t, p.N, p.S, p.tau, d_t, st));
+    if (d_t_s && p.x_ts >= 0) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_ts, p.N, p.S, p.tau, d_t_s, st));
+  }
+  char* dz = ws.c(p.o_dza); int* edz = ws.i(p.e_dza);   // dz1 is dead from here on
+  {  // 4. feats + sigma: dW for the [W + 32][W] matrix, then dz of the last trunk layer
+    const char* hl = ws.c(p.o_h[p.L - 1]); const int* ehl = ws.i(p.e_h[p.L - 1]);
+    RC(narrow_grad(p, ws, dsig, ws.c(p.o_pdsig), ws.i(p.e_dsig), gp + p.b_fs + W, st));
+    const DwMat ms = dw_begin(p, W + NARROW, W, W, false);
+    RC(dw_gemm(p, ws, ms, dfa, edfa, p.FA, 0, W, false, hl, ehl, W, 0, W, 0, st));
+    RC(dw_gemm(p, ws, ms, ws.c(p.o_pdsig), ws.i(p.e_dsig), NARROW, 0, NARROW, true, hl, ehl, W, 0, W, (size_t)W * W, st));
+    RC(dw_reduce(p, ws, ms, (size_t)(W + NARROW) * W, gp + p.w_fs, st));
+    bsp::KcArgs g;
+    g.A = dfa; g.EA = edfa; g.lda = p.FA; g.Ka = W;
+    g.A2 = ws.c(p.o_pdsig); g.EA2 = ws.i(p.e_dsig); g.lda2 = NARROW;
+    weights(g, p, pk, p.wj_tfs); g.I = P; g.J = W; g.K = W + NARROW;
+    g.C = dz; g.EC = edz; g.ldc = W;
+    dact(g, p.o_c[p.L - 1], p.o_h[p.L - 1], p.e_h[p.L - 1], W, 0, (p.L == 1) ? 30.f : 1.f);
+    RC(bsp::launch_kc(g, st));
+    RC(bias_from_colsum(p, ws, W, gp + p.b_tr[p.L - 1], st));
+  }
+  // 5. trunk, last layer to first
+  char* dz_cur = dz; int* edz_cur = edz;
+  char* dz_nxt = ws.c(p.o_dzb); int* edz_nxt = ws.i(p.e_dzb);
+  for (int i = p.L - 1; i >= 0; --i) {
+    const bool skip = (p.skip_mask >> i) & 1u;
+    const int hoff = (i > 0 && skip) ? p.Ep : 0;  // column of the h part inside W_i
+    const DwMat mt = dw_begin(p, W, p.k_tr[i], i == 0 ? p.Ep : W, false);
+    if (i == 0 || skip) RC(dw_gemm(p, ws, mt, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_pe), ws.i(p.e_pe), p.Ep, 0, p.Ep, 0, st));
+    if (i > 0) RC(dw_gemm(p, ws, mt, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_h[i - 1]), ws.i(p.e_h[i - 1]), W, 0, W, hoff, st));
+    RC(dw_reduce(p, ws, mt, (size_t)W * p.k_tr[i], gp + p.w_tr[i], st));
+    if (i == 0) break;
+    bsp::KcArgs g;
+    g.A = dz_cur; g.EA = edz_cur; g.lda = W; g.Ka = W; weights(g, p, pk, p.wj_tt[i]);
+    g.I = P; g.J = W; g.K = W; g.C = dz_nxt; g.EC = edz_nxt; g.ldc = W;
+    dact(g, p.o_c[i - 1], p.o_h[i - 1], p.e_h[i - 1], W, 0, (i - 1 == 0) ? 30.f : 1.f);
+    RC(bsp::launch_kc(g, st));
+    RC(bias_from_colsum(p, ws, W, gp + p.b_tr[i - 1], st));
+    char* t = dz_cur; dz_cur = dz_nxt; dz_nxt = t;
+    int* te = edz_cur; edz_cur = edz_nxt; edz_nxt = te;
+  }
+  return SNERF_OK;
+}
+
+// weight operand packs of the default arithmetic: table of jobs for bsp::launch_wpack (offsets into the fp32 region)
+void build_wjobs(const Plan& p, bsp::WPackTable& tb) {
+  tb.n = p.n_wjobs;
+  auto set = [&](int j, size_t src_off, int src_ld, int transposed, int m_rows, int m_cols) {
+    bsp::WPackJob& w = tb.j[j];
+    w.src_off = src_off; w.src_ld = src_ld; w.rows = p.wj_rows[j]; w.K = p.wj_K[j]; w.transposed = transposed;
+    w.dst_off = p.wj_off[j]; w.e_idx = p.wj_e[j]; w.m_rows = m_rows; w.m_cols = m_cols;
+  };
+  const int W = p.W, H = p.H;
+  for (int i = 0; i < p.L; ++i) {
+    set(p.wj_tr[i], p.w_tr[i], p.k_tr[i], 0, W, p.k_tr[i]);
+    if (i > 0) set(p.wj_tt[i], p.w_tr[i] + (((p.skip_mask >> i) & 1u) ? p.Ep : 0), p.k_tr[i], 1, W, W);
+  }
+  set(p.wj_fs, p.w_fs, W, 0, W, W);
+  set(p.wj_sig, p.w_fs + (size_t)W * W, W, 0, NARROW, W);
+  set(p.wj_tfs, p.w_fs, W, 1, W + NARROW, W);
+  set(p.wj_h1, p.w_h1, p.FA, 0, p.N1, p.FA);
+  set(p.wj_th1, p.w_h1, p.FA, 1, p.N1, p.FA);
+  set(p.wj_s2, p.w_s2, H, 0, H, H); set(p.wj_ts2, p.w_s2, H, 1, H, H);
+  set(p.wj_s3, p.w_s3, H, 0, H, H); set(p.wj_ts3, p.w_s3, H, 1, H, H);
+  set(p.wj_s4, p.w_s4, H, 0, NARROW, H); set(p.wj_ts4, p.w_s4, H, 1, NARROW, H);
+  set(p.wj_fin, p.w_fin, p.KF, 0, NARROW, p.KF); set(p.wj_tfin, p.w_fin, p.KF, 1, NARROW, p.KF);
+}
+
+}  // namespace snerf

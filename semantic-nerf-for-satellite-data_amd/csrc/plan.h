@@ -21,8 +21,11 @@ struct Plan {
   int x_sun = 0, x_t = 3, x_ts = -1, Xp = 0, FA = 0;
   // first head layers fused into one GEMM: blocks of H rows; sun block last
   int nblk = 0, blk_rgb = 0, blk_sem = -1, blk_beta = -1, blk_sbeta = -1, blk_sun = -1;
-  int N1 = 0;   // rows of the fused first-head-layer matrix
-  int KF = 0;   // contraction length of the block-diagonal final-layer matrix (all blocks but sun)
+  int N1 = 0;   // rows of the fused first-head-layer matrix = KF + H
+  int KF = 0;   // contraction length of the block-diagonal final-layer matrix: all blocks but sun, (nblk - 1) H -- in the
+                // block-scaled plane layout (fmt 1) rounded up to 128 so that the sun block starts on an exponent block
+  int sun_col = 0;  // first row of the sun block in the fused first-layer matrix / its column in the h1 buffer (= KF)
+  int Wf = 0;   // column of the extras block [sun | t | t_s] behind the feats columns: W (fmt 1: rounded up to 128)
   bool rgb_t = false, sem_t = false, sem_ts = false, sbeta_ts = false;
   // final-layer output columns inside the NARROW-wide buffer
   static constexpr int col_rgb = 0, col_beta = 3, col_sbeta = 4, col_sem = 5;
@@ -62,6 +65,20 @@ struct Plan {
   // backward scratch
   size_t o_dza = 0, o_dzb = 0, o_dsa = 0, o_dsb = 0, o_dsig = 0, o_dfin = 0, o_dsun = 0;
   size_t o_colsum = 0, o_colsum2 = 0, o_slab = 0, o_slab2 = 0, o_skyslab = 0;
+  // ---- block-scaled plane layout (fmt 1; csrc/bsp.h): every activation buffer above holds G16 planes instead of fp32
+  //      (same bytes) and has an exponent table; the 32-wide head gradients also exist as planes
+  size_t e_pe = 0, e_fa = 0, e_h1 = 0, e_s2 = 0, e_s3 = 0, e_h[SNERF_MAX_LAYERS] = {0};
+  size_t e_dza = 0, e_dzb = 0, e_dsa = 0, e_dsb = 0, e_dsig = 0, e_dfin = 0, e_dsun = 0;
+  size_t o_pdsig = 0, o_pdfin = 0, o_pdsun = 0;          // planes [Pp][32] of the narrow gradients
+  // weight operand packs (WF16) behind the fp32 region of the packed buffer
+  enum { WJ_MAX = 48 };
+  int n_wjobs = 0;
+  int wj_tr[SNERF_MAX_LAYERS] = {0}, wj_tt[SNERF_MAX_LAYERS] = {0};
+  int wj_fs = 0, wj_sig = 0, wj_tfs = 0, wj_h1 = 0, wj_th1 = 0, wj_s2 = 0, wj_ts2 = 0, wj_s3 = 0, wj_ts3 = 0, wj_s4 = 0, wj_ts4 = 0,
+      wj_fin = 0, wj_tfin = 0;
+  unsigned long long wj_off[WJ_MAX] = {0};   // byte offset of each pack inside the plane region
+  int wj_rows[WJ_MAX] = {0}, wj_K[WJ_MAX] = {0}, wj_e[WJ_MAX] = {0};
+  size_t wp_bytes = 0;                       // plane region size; then WJ_MAX exponents (int) and WJ_MAX |max| words
   int h1w = 0;       // width of the h1 buffer in this pass (N1, or H for the sc pass)
   int maxw = 0;      // widest dz buffer
   int nrb = 0;       // 32-row blocks (colsum partials)
@@ -72,6 +89,7 @@ struct Plan {
 
 struct DwSplit { int ns = 1; int k_split = 32; };
 DwSplit dw_choose(int P, int rows, int cols, bool narrow_rows);
+DwSplit dw_choose_bsp(int P, int rows, int cols, bool narrow_rows);
 
 // returns SNERF_OK or an error (message via set_error)
 int make_plan(const SnerfDesc* d, Plan* pl);

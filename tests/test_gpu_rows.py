@@ -325,8 +325,8 @@ def test_fused_adam_none_gradients_and_per_parameter_steps():
     assert [int(float(tsd["state"][i]["step"])) for i in range(5)] == oh.steps
     hsd = oh.state_dict()
     for i in range(5):
-        assert rel_err(hsd["state"][i]["exp_avg"].cpu(), tsd["state"][i]["exp_avg"].cpu()) <= 1e-5
-        assert rel_err(hsd["state"][i]["exp_avg_sq"].cpu(), tsd["state"][i]["exp_avg_sq"].cpu()) <= 1e-5
+        assert rel_err(hsd["state"][i]["exp_avg"].cpu(), tsd["state"][i]["exp_avg"].cpu()) <= 1e-4
+        assert rel_err(hsd["state"][i]["exp_avg_sq"].cpu(), tsd["state"][i]["exp_avg_sq"].cpu()) <= 1e-4
     # torch's checkpoint into FlatAdam and FlatAdam's into torch: the next step agrees again
     p2 = [torch.nn.Parameter(t.detach().clone()) for t in pt]
     o2 = FlatAdam(p2, lr=1e-2)
