@@ -46,11 +46,12 @@ DwSplit dw_choose(int P, int rows, int cols, bool narrow_rows) {
   return d;
 }
 
-// split-K choice for the plane dW kernel: 256 x 256 tiles, one workgroup per CU -> tiles x splits ~ 512 (two rounds),
-// splits of whole 128-point exponent blocks, at most 16384 points each
+// split-K choice for the plane dW kernel: 256 x 256 tiles, one workgroup per CU -> tiles x splits ~ 256 (ONE round of
+// the chip: every workgroup writes a 256 KB slab, so the slab traffic of a launch is 64 MB however the matrix is shaped;
+// two rounds doubled it and the reduction that follows), splits of whole 128-point exponent blocks, <= 16384 points each
 DwSplit dw_choose_bsp(int P, int rows, int cols, bool narrow_rows) {
   const int tiles = (narrow_rows ? 1 : (rows + 255) / 256) * ((cols + 255) / 256);
-  int ns = (512 + tiles / 2) / tiles;
+  int ns = (256 + tiles / 2) / tiles;
   const int ns_max = P / 1024 > 1 ? P / 1024 : 1;
   if (ns > ns_max) ns = ns_max;
   if (ns < 1) ns = 1;

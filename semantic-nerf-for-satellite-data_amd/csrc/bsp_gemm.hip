@@ -659,11 +659,13 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
       e_cur = e_new;
     }
   };
-#ifdef BSP_DW_PINGPONG
+#ifndef BSP_DW_LOCKSTEP
   if constexpr (TI == 256) {
     // Ping-pong: the eight waves form two groups (tile rows 0-127 / 128-255; one wave of each per SIMD) that run the same
     // two-phase step -- M: request stage s + 2, read the 24 fragments of stage s | C: 24 MFMAs on those registers -- one
-    // phase apart, with a workgroup barrier after every phase.
+    // phase apart, with a workgroup barrier after every phase.  While one wave of a SIMD issues its MFMAs back to back the
+    // other does its LDS reads and DMA issue; in lockstep (all eight waves request, read, compute together) the three
+    // costs add up: measured 336 us lockstep / 311 us ping-pong at 262,144 x 512 x 512 (-DBSP_DW_LOCKSTEP builds the former).
     //   phase:    0      1      2      3     ...
     //   group 0:  M(0)   C(0)   M(1)   C(1)
     //   group 1:  -      M(0)   C(0)   M(1)
