@@ -9,6 +9,13 @@ One step = one full optimiser step of BASELINE.json configs[1] ("JAX_068 semanti
 samples, fp32") per GPU: on-device batch sampling -> main + solar-correction forward -> SatNerfLoss +
 solar correction + SemanticLoss (fused HIP loss kernels) -> backward -> flat gradient all-reduce (RCCL,
 N > 1) -> Adam.  Weak scaling: 4096 rays per GPU.  Prints ONE JSON line (rank 0).
+
+Besides the contract fields the line carries, all measured in the same run (N = 1):
+  roofline             dominant kernel (the K-contiguous dense-layer GEMM): algorithmic FLOPs / HIP-event duration against the
+                       dense fp16 MFMA peak (`frac`), the matrix-pipe occupancy of the three-product arithmetic next to it
+  cpu_baseline         the CPU oracle on the host cores, bounded sample
+  reference_gpu_eager  the same restatement on cuda:0 with stock PyTorch-ROCm eager ops (north_star's denominator)
+  inference            forward-only rays/s: lean full-frame path and the reference-shaped batched_inference
 """
 import argparse
 import ctypes as C
@@ -108,11 +115,41 @@ def eager_gpu_baseline(rays, samples, device, steps=3):
             "sample": f"{steps} full train steps of {rays} rays x {samples} samples, render_chunk_size 40960 points"}
 
 
+def inference_rates(pipe, cfgs, device, samples, n_rays=40960 * 4):
+    """Forward-only rays/s (SURVEY 8(d) asks for it next to the training number): one "image" of n_rays rays through
+    (a) lean_inference -- rgb + depth + label only, no solar-correction pass, written in place per chunk -- and
+    (b) batched_inference, the reference-shaped full result dict incl. the sc pass (eval/utils/util.py:13-42);
+    render_chunk_size = the reference default 40960 rays."""
+    from snerf_amd.eval.utils.util import batched_inference, lean_inference
+    from snerf_amd.framework.datasets import GpuRayBank
+    bank = GpuRayBank.synthetic(n_rays, 19, 5, 123, device=device)
+    rays, extras = bank.t["rays"], bank.t["extras"]
+    old = cfgs.pipeline.render_chunk_size
+    cfgs.pipeline.render_chunk_size = 40960
+    out = {}
+    try:
+        for name, fn in (("lean", lambda: lean_inference(cfgs, pipe.renderer, pipe.models, rays, extras)),
+                         ("batched", lambda: batched_inference(cfgs, pipe.renderer, pipe.models, rays, extras))):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            out[f"{name}_rays_per_s"] = n_rays / (time.perf_counter() - t0)
+            del r
+            torch.cuda.empty_cache()
+    finally:
+        cfgs.pipeline.render_chunk_size = old
+    out.update(unit="rays/s", rays=n_rays, samples=samples, render_chunk_size=40960,
+               lean="rgb + depth + semantic_label, main pass only", batched="all results of render_rays incl. solar-correction pass")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--rays", type=int, default=4096, help="rays per GPU")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,7 +158,8 @@ def main():
     ap.add_argument("--mfma", default="f16x2", choices=["split3", "f16x2", "fp32", "split2", "bf16", "split3_bwd2"],
                     help="matrix arithmetic: f16x2 (default, headline) and split3 are fp32-class; split2 / split3_bwd2 / bf16 are the REDUCED-precision "
                          "modes of BASELINE configs[2]/[4] (reported under their own dtype, never as the fp32 headline)")
-    ap.add_argument("--eager-gpu-baseline", action="store_true", help="also time the oracle with stock PyTorch ops on the GPU")
+    ap.add_argument("--no-eager-gpu-baseline", action="store_true", help="skip the stock-PyTorch-on-GPU denominator (3 steps)")
+    ap.add_argument("--no-inference", action="store_true", help="skip the forward-only (full-frame inference) leg")
     args = ap.parse_args()
 
     import snerf_amd  # noqa: F401
@@ -154,12 +192,18 @@ def main():
         loop.step(step)
         step += 1
     barrier()
+    # per-step marks on the compute stream (no host sync inside the timed region): the median step time next to the mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         out = loop.step(step)
+        marks[i + 1].record()
         step += 1
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     # Roofline phase (after the timed region, so the headline number carries no event overhead): the same steps with
     # the main and solar-correction passes serialised -- in the timed region their kernels overlap on two HIP streams,
     # which would stretch every per-kernel duration -- and every GEMM launch bracketed by HIP events on its stream.
@@ -195,18 +239,22 @@ def main():
     rays_total = args.rays * world * args.steps
     value = rays_total / dt
     flops_step_gpu = FLOPS_PER_SAMPLE_TRAIN * args.rays * args.samples
+    reduced = {"split3_bwd2": "f32 forward / REDUCED backward", "split2": "REDUCED (fp32 as two bf16, ~16 bits)", "bf16": "bf16 (REDUCED)"}
     line = {
-        "metric": "train rays/sec (4096 rays x 64 samples)", "value": value, "unit": "rays/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
-        # storage and accumulation are fp32 in every mode; `arithmetic` says how the products are formed
-        "dtype": {"f16x2": "f32", "split3": "f32", "fp32": "f32", "split3_bwd2": "f32 forward / REDUCED backward",
-                  "split2": "REDUCED (fp32 as two bf16, ~16 bits)", "bf16": "bf16 (REDUCED)"}[mode],
-        "arithmetic": {"split3": "fp32 storage and accumulate; products on bf16 MFMA via 3-plane splits, fp32-level accuracy",
-                       "f16x2": "fp32 storage and accumulate; products on fp16 MFMA via 2-plane splits of power-of-two-scaled operands, fp32-level accuracy",
-                       "fp32": "v_mfma_f32_32x32x2_f32", "split2": "REDUCED: f32 storage/accumulate, operands as 2 bf16 planes (~16 bits, torch 'high')",
-                       "bf16": "REDUCED: bf16 operands, f32 accumulate and storage (torch 'medium' / precision=16)",
-                       "split3_bwd2": "f32 forward (3-plane splits, fp32-level results); REDUCED backward: 2 bf16 planes (~16 bits) in dX / dW"}[mode],
+        "metric": f"train rays/sec ({args.rays} rays x {args.samples} samples)", "value": value, "unit": "rays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": median_ms,
+        "higher_is_better": True, "scaling": "weak",
+        # BASELINE.md holds no published number for this metric (the reference publishes none): null by the contract.  The
+        # north-star ratio against the reference's single-GPU PyTorch path measured in THIS run is `vs_reference_gpu_eager`.
+        "vs_baseline": None,
+        "dtype": reduced.get(mode, "f32"),
+        "arithmetic": {
+            "f16x2": "fp32-class: activations stored as two fp16 planes with one power-of-two exponent per 128 x 128 block (same bytes as "
+                     "fp32), products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate",
+            "split3": "fp32 storage and accumulate; products on bf16 MFMA via 3-plane splits, fp32-level accuracy",
+            "fp32": "v_mfma_f32_32x32x2_f32", "split2": "REDUCED: f32 storage/accumulate, operands as 2 bf16 planes (~16 bits, torch 'high')",
+            "bf16": "REDUCED: bf16 operands, f32 accumulate and storage (torch 'medium' / precision=16)",
+            "split3_bwd2": "f32 forward (3-plane splits, fp32-level results); REDUCED backward: 2 bf16 planes (~16 bits) in dX / dW"}[mode],
         "data": "synthetic",
         "config": {"workload": "JAX_068 semantic pipeline (configs[1]): RSSemanticNeRF fc_units=512 x 8 layers, C=5, "
                                f"{args.rays} rays x {args.samples} samples per GPU, fp32, main + solar-correction pass, "
@@ -216,50 +264,57 @@ def main():
                    "parallelism": f"dp{world}", "final_loss": loss,
                    "streams": "main pass and solar-correction pass on two HIP streams" if not args.serial_passes else "single stream"},
     }
+    if world > 1:   # what the collective layer actually was (the driver can check the rank count RCCL saw)
+        import torch.distributed as dist
+        line["config"]["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                         "nccl_version": ".".join(map(str, torch.cuda.nccl.version())) if dist.get_backend() == "nccl" else None,
+                                         "gradient_bucket_floats": int(getattr(loop.optimizer, "numel", 0))}
     step_tflops = flops_step_gpu * args.steps / dt / 1e12  # per GPU, algorithmic (SURVEY 8d figure)
     if prof is not None:
         x6 = mode != "fp32"
-        # dominant kernel = variant 0: the K-contiguous launches (forward X.W^T and dX; gemm_wide_kernel), ~61 % of device time
+        # dominant kernel = variant 0: the K-contiguous dense-layer launches (forward X.W^T and dX), ~63 % of device time
         ms, fl, n = prof.ms[0], prof.flops[0], prof.launches[0]
-        fp32_eq = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        fam_ms = sum(prof.ms[v] for v in range(3)); fam_fl = sum(prof.flops[v] for v in range(3))
-        # split kernel: the contraction at this accuracy IS `mult` 16-bit MFMA products per fp32 product (3 on fp16
-        # planes of scaled operands, 6 on bf16 planes), so the kernel's algorithmic work is mult x (2 I J K) flops,
-        # priced against the dense bf16/fp16 MFMA peak
+        alg = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0          # algorithmic: 2 I J K per launch (SURVEY 8d's FLOPs)
         mult, peak = ({"split3": 6.0, "f16x2": 3.0, "split2": 3.0, "bf16": 1.0, "split3_bwd2": 4.0}[mode], BF16_MFMA_PEAK_TFLOPS) if x6 else (1.0, FP32_MFMA_PEAK_TFLOPS)
-        achieved = fp32_eq * mult
-        # HBM bytes per launch of that kernel from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
-        # the MI355X guide), measured on this exact workload: profiles/r01/pmc_hbm_traffic.md
-        traffic = 1.298e9 if (mode == "f16x2" and args.rays == 4096 and args.samples == 64) else None
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")   # PMC passes of this workload (see the file's provenance)
+        if os.path.isfile(tf) and mode == "f16x2" and args.rays == 4096 and args.samples == 64:
+            try:
+                traffic = json.load(open(tf)).get("kc_bytes_per_launch")
+            except Exception:
+                traffic = None
         line["roofline"] = {
-            "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "kernel": (("snerf::gemm_wide_kernel (128x256 tile; two fp16 planes of power-of-two-scaled fp32 operands, hh + hl + lh = 3 x "
-                        "v_mfma_f32_32x32x16_f16 per 32x32x16 block, fp32 accumulate; forward X.W^T and dX launches; the two launches per "
-                        "step whose width does not fit run the 128x128 tile of gemm_x6_kernel and are averaged in)" if mode == "f16x2" else
-                        "snerf::gemm_x6_kernel<false,true,NP,128> (split-bf16: NP bf16 planes per fp32 operand, 6 / 3 / 1 x v_mfma_f32_32x32x16_bf16 per "
-                        "32x32x16 block for NP = 3 / 2 / 1, fp32 accumulate; forward X.W^T and dX launches)") if x6 else
-                       "snerf::gemm_kernel<128,128,64,64,false,false> (v_mfma_f32_32x32x2_f32)"),
-            "fp32_equivalent_tflops": fp32_eq, "vs_fp32_mfma_peak": fp32_eq / FP32_MFMA_PEAK_TFLOPS,
+            "bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s",
+            "frac": alg / peak,                              # ALGORITHMIC fraction: SURVEY 8(d) FLOPs / dense 16-bit MFMA peak
+            "frac_mfma_issued": alg * mult / peak,           # matrix-pipe occupancy: `mult` 16-bit MFMA products per fp32 product
+            "mfma_products_per_fp32_product": mult, "traffic": traffic,
+            "kernel": ("snerf::bsp::gemm_kc_kernel (128 x 256 tile; A = fp16 planes by LDS-DMA, W = fragment-ordered planes straight from L2; "
+                       "3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block; epilogue writes planes + block exponents)" if mode == "f16x2" else
+                       ("snerf::gemm_x6_kernel<false,true,NP,128> (split-bf16 planes from fp32 storage)" if x6 else
+                        "snerf::gemm_kernel<128,128,64,64,false,false> (v_mfma_f32_32x32x2_f32)")),
+            "vs_fp32_mfma_peak": alg / FP32_MFMA_PEAK_TFLOPS,
             "launches": int(n), "avg_launch_ms": ms / max(n, 1),
-            "measured_over": f"{prof_steps} extra steps after the timed region, main and sc pass serialised (SNERF_OVERLAP_SC=0 behaviour)",
-            "all_128x128_gemms": {"ms_per_step": fam_ms / max(prof_steps, 1), "fp32_equivalent_tflops": fam_fl / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0},
+            "measured_over": f"{prof_steps} extra steps after the timed region, main and sc pass serialised (SNERF_OVERLAP_SC=0 behaviour), "
+                             "HIP events on the launch stream around every GEMM launch",
             "per_variant": {(_lib.PROFILE_VARIANTS[v]): {
                 "launches": int(prof.launches[v]), "avg_ms": prof.ms[v] / max(prof.launches[v], 1),
-                "fp32_equivalent_tflops": (prof.flops[v] / (prof.ms[v] * 1e-3) / 1e12) if prof.ms[v] > 0 else 0.0}
+                "algorithmic_tflops": (prof.flops[v] / (prof.ms[v] * 1e-3) / 1e12) if prof.ms[v] > 0 else 0.0}
                 for v in range(4) if prof.launches[v] > 0},
-            "whole_step_fp32_equivalent_tflops": step_tflops, "whole_step_vs_fp32_mfma_peak": step_tflops / FP32_MFMA_PEAK_TFLOPS,
+            "whole_step_algorithmic_tflops": step_tflops, "whole_step_frac": step_tflops / peak,
         }
     else:
-        line["roofline"] = {"bound": "mfma", "achieved": step_tflops, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                            "frac": step_tflops / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+        line["roofline"] = {"bound": "mfma", "achieved": step_tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": step_tflops / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
                             "kernel": "whole step (algorithmic FLOPs / wall time); per-kernel timing disabled"}
+    if world == 1 and not args.no_inference:
+        line["inference"] = inference_rates(pipe, cfgs, device, args.samples)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.samples)
-    if world == 1 and args.eager_gpu_baseline:
+    if world == 1 and not args.no_eager_gpu_baseline:
         del loop, pipe
         torch.cuda.empty_cache()
-        line["torch_eager_gpu_baseline"] = eager_gpu_baseline(args.rays, args.samples, device)
-        line["torch_eager_gpu_baseline"]["speedup_of_value"] = value / line["torch_eager_gpu_baseline"]["value"]
+        line["reference_gpu_eager"] = eager_gpu_baseline(args.rays, args.samples, device)
+        line["vs_reference_gpu_eager"] = value / line["reference_gpu_eager"]["value"]
     print(json.dumps(line))
 
 

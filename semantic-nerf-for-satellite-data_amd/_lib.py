@@ -91,8 +91,8 @@ class SnerfProfile(C.Structure):
     _fields_ = [("ms", C.c_double * 4), ("flops", C.c_double * 4), ("launches", C.c_int64 * 4)]
 
 
-PROFILE_VARIANTS = ("K-contiguous operands (fwd X.W^T, dX=dZ.W): gemm_wide_kernel 128x256 tile, or 128x128", "mixed layouts (unused)",
-                    "row-contiguous operands (dW=dZ^T.X, split-K): 256x256 or 128x128 tile", "32-wide head variants (fp32 MFMA)")
+PROFILE_VARIANTS = ("K-contiguous dense layers (forward X.W^T and dX = dZ.W): gemm_kc_kernel, 128 x 256 tile", "mixed layouts (unused)",
+                    "weight gradients (dW = dZ^T.X, split-K slabs): gemm_dw_kernel, 256 x 256 tile", "32-wide head variants (forward + dW)")
 
 _lib = None
 
