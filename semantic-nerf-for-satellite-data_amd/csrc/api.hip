@@ -162,7 +162,7 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   if (d->skip_mask & 1u) return bad("layer 0 cannot be a skip layer");
   p.N = d->n_rays; p.S = d->n_samples; p.P = p.N * p.S; p.Pp = round_up(p.P, 128);
   p.W = d->fc_units; p.H = d->feat_last; p.L = d->fc_layers; p.F = d->n_freq;
-  p.E = p.F > 0 ? 6 * p.F : 3; p.Ep = round_up(p.E, 16);  // k-tiles (16) never straddle the [gamma | h] segments
+  p.E = p.F > 0 ? 6 * p.F : 3; p.Ep = round_up(p.E, 32);  // LDS stages (32 k) never straddle the [gamma | h] segments
   p.tau = d->t_dim; p.C = d->n_classes;
   p.siren = d->siren != 0; p.sem_sigmoid = d->sem_sigmoid != 0;
   p.train = (d->flags & SNERF_FLAG_TRAIN) != 0; p.sc = (d->flags & SNERF_FLAG_SC_PASS) != 0;
@@ -185,7 +185,7 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.sbeta_ts = sbeta && sep_ts;
   p.x_sun = 0; p.x_t = 3; p.x_ts = sep_ts ? 3 + p.tau : -1;
   p.Xp = round_up(3 + p.tau + (sep_ts ? p.tau : 0), 16);  // FA % 16 == 0: weight planes are stored in 16-k tiles
-  if (p.fmt == 1 && ((p.H & 15) || p.Xp != 16)) return bad("the default arithmetic needs feat_last % 16 == 0 and 3 + t_dim (x2 with separate t_s) <= 16; use SNERF_FLAG_SPLIT3");
+  if (p.fmt == 1 && ((p.H & 15) || (p.W & 31) || p.Xp != 16)) return bad("the default arithmetic needs feat % 32 == 0, feat_last % 16 == 0 and 3 + t_dim (x2 with separate t_s) <= 16; use SNERF_FLAG_SPLIT3");
   p.Wf = p.fmt == 1 ? round_up(p.W, 128) : p.W;         // extras block on an exponent-block boundary
   p.FA = p.Wf + p.Xp;
   int nb = 0;

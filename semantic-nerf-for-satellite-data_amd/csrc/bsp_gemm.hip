@@ -87,9 +87,9 @@ __device__ __forceinline__ int kc_exp_of_step(const KcArgs& p, int rb, int s, in
 // time (fragment reads + DMA fills, 144 KB per step of two co-resident workgroups) and the six DMA pieces per wave and
 // step cost the issuing wave ~80 cycles each (ablation builds of tools/ablate: 72 of 460 us per launch); the weight
 // tiles were 2/3 of both.  This form moves 80 KB per step through LDS and issues two pieces per wave.
-constexpr int KC_A = 128 * 64, KC_RING = 3;
+constexpr int KC_A = 128 * 128, KC_RING = 3;               // one stage: 128 rows x 32 k (two 16-column groups, 128 B per row)
 constexpr int KC_STRIP = 32 * 68 * 4;                      // one wave's 32 x (64 + 4) fp32 transposition strip
-constexpr int KC_RINGB = KC_RING * KC_A;                   // 32 KiB
+constexpr int KC_RINGB = KC_RING * KC_A;                   // 48 KiB
 constexpr int KC_TAIL = (KC_RINGB > 4 * KC_STRIP) ? KC_RINGB : 4 * KC_STRIP;   // small tables behind ring / strips
 #ifdef BSP_ABL_ONEWG
 constexpr int KC_LDS = KC_TAIL + 128 * 4 + 64 + 64 * 1024;   // one workgroup per CU (diagnostics)
@@ -115,24 +115,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   const unsigned long long sc0 = __builtin_amdgcn_s_memtime();
 #endif
 
-  // ---- A: per-lane DMA sources (two 1 KiB pieces of the 128 x 64 B stage per wave)
+  // ---- A: per-lane DMA sources.  A stage is 32 k deep = 128 rows x 128 B (two column groups, the tensor's own byte
+  // order); its sixteen 1 KiB pieces (8 rows each) go to the waves round-robin, four per wave, two per 16-deep sub-step.
+  // The 16 B chunk c of a row sits at position c ^ ((row >> 1) & 7): a quarter-wave of ds_read_b128 (eight lanes, eight
+  // consecutive rows, one chunk) then covers four distinct positions twice -> all 32 banks in two passes, no conflict.
+  const int nst = (nks + 1) >> 1, nst1 = nks1 >> 1;          // stages; stages of the first segment (Ka % 32 == 0 if two)
   const srd_t srdA = make_srd(p.A + ((size_t)i0 * p.lda + p.a_col0) * 4,
                               clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda + p.Ka) * 4ull : 0ull));
   const srd_t srdA2 = make_srd(p.A2 + ((size_t)i0 * p.lda2 + p.a2_col0) * 4,
                                clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda2 + (p.K - p.Ka)) * 4ull : 0ull));
-  unsigned voA[2], voA2[2];
+  unsigned voA[4], voA2[4];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int row = 64 * q + (t >> 2);
-    const unsigned c = (unsigned)((t & 3) ^ ((row >> 2) & 3));
+  for (int q = 0; q < 4; ++q) {
+    const int row = 8 * (wave + 4 * q) + (lane >> 3);
+    const unsigned c = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
     const bool in = i0 + row < p.I;
     voA[q] = in ? (unsigned)row * (unsigned)p.lda * 4u + 16u * c : OOB;
     voA2[q] = in ? (unsigned)row * (unsigned)p.lda2 * 4u + 16u * c : OOB;
   }
   char* const dst0 = lds + wave * 1024;
-  auto issueA = [&](int s, int slot, int q) {
-    const bool live = s < nks, seg2 = s >= nks1;
-    dma16(seg2 ? srdA2 : srdA, dst0 + slot * KC_A + 4096 * q, seg2 ? voA2[q] : voA[q], live ? (unsigned)(seg2 ? s - nks1 : s) * 64u : OOB);
+  auto issueA = [&](int S, int slot, int q) {
+    const bool live = S < nst, seg2 = p.Ka < p.K && S >= nst1;
+    dma16(seg2 ? srdA2 : srdA, dst0 + slot * KC_A + 4096 * q, seg2 ? voA2[q] : voA[q], live ? (unsigned)(seg2 ? S - nst1 : S) * 128u : OOB);
   };
   // ---- W: fragment-ordered pack; unit (ks, rb32) = 2 KiB = [plane][lane][16 B]; this wave reads units rb32 = u0, u0 + 1
   const srd_words srdW = make_srd_words(p.W, p.w_bytes);
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:2048" : "=v"(b.h[1]) : "v"(voW), "s"(srdW), "s"(so));
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:3072" : "=v"(b.l[1]) : "v"(voW), "s"(srdW), "s"(so));
   };
-  // everything but the six youngest requests (= the next step's) has landed; names the fragments so that no use of them
+  // everything but the six youngest requests (= the next sub-step's) has landed; names the fragments so that no use of them
   // can be scheduled above the wait
   auto wait_b = [&](BFrag& b) {
     asm volatile("s_waitcnt vmcnt(6)" : "+v"(b.h[0]), "+v"(b.l[0]), "+v"(b.h[1]), "+v"(b.l[1])::"memory");
@@ -165,14 +169,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti, sA - 1, nks1) : eA;
   const int eBp = sB < nks ? kc_exp_of_step(p, ti, sB - 1, nks1) : eB;
   const int e_last = kc_exp_of_step(p, ti, nks - 1, nks1);
-  // Both operands are requested TWO steps ahead.  vm-counter order: [W(0) A(0)] [W(1) A(1)], then per step s:
-  // [W(s + 2) x 4] [A(s + 2) x 2] -- at the top of step s everything of step s + 1 (six requests) may be outstanding:
-  // s_waitcnt vmcnt(6).  (One step ahead for W measured 82 us of L2 latency on the critical path of a 339 us loop.)
+  // Both operands are requested ahead: W two sub-steps, A two stages.  vm-counter order: [W(0) A(0) x 4] [W(1) A(1) x 4],
+  // then per sub-step s = 2 S + u: [W(s + 2) x 4] [two pieces of A(S + 2)] -- at the top of sub-step s the six requests
+  // of sub-step s - 1 may be outstanding and everything older has landed, which covers W(s) and all of stage S (issued
+  // during stage S - 2): s_waitcnt vmcnt(6).  (Three sub-steps ahead for W, 16 more registers: 480 vs 466 us.)  (One step ahead for W measured 82 us of L2 latency on the critical path of a 339 us loop.)
   BFrag bq0, bq1, bq2;
   loadB(0, bq0);
-  issueA(0, 0, 0); issueA(0, 0, 1);
+  issueA(0, 0, 0); issueA(0, 0, 1); issueA(0, 0, 2); issueA(0, 0, 3);
   loadB(1, bq1);
-  issueA(1, 1, 0); issueA(1, 1, 1);
+  issueA(1, 1, 0); issueA(1, 1, 1); issueA(1, 1, 2); issueA(1, 1, 3);
   if (wave == 0) { etab[sA] = eA; etab[sB] = eB; }
   const unsigned long long chg0 = __builtin_amdgcn_ballot_w64(eA != eAp), chg1 = __builtin_amdgcn_ballot_w64(eB != eBp);
 
@@ -184,16 +189,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
 
-  // A fragment addresses: lane -> (row l & 31, k half l >> 5); chunk (2 pl + half) sits at position chunk ^ ((row >> 2) & 3)
-  const int rowl = lane & 31, kh = lane >> 5, swz = (rowl >> 2) & 3;
-  const unsigned fo0 = (unsigned)rowl * 64u + (unsigned)(((0 + kh) ^ swz) << 4);
-  const unsigned fo1 = (unsigned)rowl * 64u + (unsigned)(((2 + kh) ^ swz) << 4);
+  // A fragment addresses: lane -> (row l & 31, k half l >> 5); chunk (4 u + 2 pl + half) of sub-step u sits at position
+  // chunk ^ ((row >> 1) & 7)
+  const int rowl = lane & 31, kh = lane >> 5, swz = (rowl >> 1) & 7;
+  unsigned fo[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) fo[u][pl] = (unsigned)rowl * 128u + (unsigned)(((4 * u + 2 * pl + kh) ^ swz) << 4);
 
 #ifdef BSP_ABL_STAMP
   unsigned long long st_wait = 0, st_vm = 0;
 #endif
-  // one k-step: MFMAs of step s on (LDS slot, weight registers `bc`); `bn` receives the weight fragments of step s + 2
-  auto step = [&](int s, int slot, BFrag& bc, BFrag& bn) {
+  // one 16-deep sub-step s = 2 S + u of stage S: MFMAs on (LDS slot, weight registers `bc`); `bn` receives the weight
+  // fragments of sub-step s + 2.  The workgroup barrier comes once per STAGE (u == 0).
+  auto step = [&](int s, int slot, int u, BFrag& bc, BFrag& bn) {
 #ifdef BSP_ABL_STAMP
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #ifdef BSP_ABL_STAMP
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
 #endif
-    barrier_raw();                       // stage s visible to all; everybody has finished reading stage s - 2
+    if (u == 0) barrier_raw();           // stage S visible to all; everybody has finished reading stage S - 1
 #ifdef BSP_ABL_STAMP
     const unsigned long long c2 = __builtin_amdgcn_s_memtime();
     st_vm += c1 - c0; st_wait += c2 - c1;
@@ -227,24 +237,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #ifdef BSP_ABL_NOLDSREAD
       ah[mi] = __builtin_bit_cast(f16x8, bc.h[mi & 1]); al[mi] = __builtin_bit_cast(f16x8, bc.l[mi & 1]);
 #else
-      ah[mi] = ldsfrag(st + 2048 * mi + fo0);
-      al[mi] = ldsfrag(st + 2048 * mi + fo1);
+      ah[mi] = ldsfrag(st + 4096 * mi + fo[u][0]);
+      al[mi] = ldsfrag(st + 4096 * mi + fo[u][1]);
 #endif
     }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
 #ifdef BSP_ABL_NOMFMA
-      asm volatile("" ::"v"(ah[mi]), "v"(al[mi]), "v"(bc.h[0]), "v"(bc.l[0]), "v"(bc.h[1]), "v"(bc.l[1]));
-#else
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj)
-        acc[mi][nj] = mfma3(ah[mi], al[mi], __builtin_bit_cast(f16x8, bc.h[nj]), __builtin_bit_cast(f16x8, bc.l[nj]), acc[mi][nj]);
-#endif
+    for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(ah[mi]), "v"(al[mi]), "v"(bc.h[0]), "v"(bc.l[0]), "v"(bc.h[1]), "v"(bc.l[1]));
+#else
+    // The three products of an accumulator tile (smallest first: hi*lo, lo*hi, hi*hi) are issued eight MFMAs apart, one
+    // term at a time over the eight tiles: a dependent MFMA straight behind its producer waits for the result to leave the
+    // pipe, and with the SIMD's other wave in its epilogue nothing fills that bubble.
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj)
+          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 1 ? al[mi] : ah[mi],
+                                                               __builtin_bit_cast(f16x8, term == 0 ? bc.l[nj] : bc.h[nj]), acc[mi][nj], 0, 0, 0);
 #ifndef BSP_ABL_NODMA
-      if (mi == 1) issueA(s + 2, (slot + 2) % KC_RING, 0);   // the two pieces of stage s + 2, under the MFMAs
-      if (mi == 2) issueA(s + 2, (slot + 2) % KC_RING, 1);
+        if (term == 1 && mi == 1) issueA((s >> 1) + 2, (slot + 2) % KC_RING, 2 * u);   // two of the four pieces of stage S + 2,
+        if (term == 2 && mi == 0) issueA((s >> 1) + 2, (slot + 2) % KC_RING, 2 * u + 1);   // under the MFMAs
 #endif
-    }
+      }
+#endif
 #if !defined(BSP_ABL_NOBLOAD) && !defined(BSP_ABL_NOLDSREAD) && !defined(BSP_ABL_NOMFMA) && !defined(BSP_ABL_NODMA)
     // pin the order in the emitted code: the weight loads of step s + 1 go out FIRST (left alone, the scheduler sinks them
     // to the end of the step to save registers and the next step then waits for L2 with nothing to do), then the eight
@@ -261,10 +278,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   // The k-loop runs at raised priority: while the SIMD's other wave (the co-resident workgroup) is in its VALU-heavy
   // epilogue, MFMA issue goes first and the epilogue stream fills the 24 of every 32 cycles the matrix pipe leaves free.
   __builtin_amdgcn_s_setprio(2);
-  for (int s = 0; s < nks; s += 3) {
-    step(s, 0, bq0, bq2);
-    if (s + 1 < nks) step(s + 1, 1, bq1, bq0);
-    if (s + 2 < nks) step(s + 2, 2, bq2, bq1);
+  for (int s = 0; s < 2 * nst; s += 6) {   // an odd count of 16-deep steps runs one sub-step on zero weights
+    step(s, 0, 0, bq0, bq2);
+    step(s + 1, 0, 1, bq1, bq0);
+    if (s + 2 < 2 * nst) { step(s + 2, 1, 0, bq2, bq1); step(s + 3, 1, 1, bq0, bq2); }
+    if (s + 4 < 2 * nst) { step(s + 4, 2, 0, bq1, bq0); step(s + 5, 2, 1, bq2, bq1); }
   }
   __builtin_amdgcn_s_setprio(0);
   wait_vm<0>();        // rejected requests behind the last stage write zeros into the ring: drain before re-using it
@@ -801,6 +819,7 @@ static int check_kc(const KcArgs& a, bool narrow) {
   if (a.I <= 0 || a.J <= 0 || a.K <= 0) return bad("empty problem");
   if ((a.K & 15) || (a.Ka & 15) || a.Ka <= 0 || a.Ka > a.K || a.K > 2048) return bad("K and Ka must be multiples of 16, K <= 2048");
   if ((a.lda & 15) || (a.a_col0 & 15) || a.a_col0 + a.Ka > a.lda) return bad("A segment does not fit its tensor (16-column groups)");
+  if (a.Ka < a.K && (a.Ka & 31)) return bad("two A segments: the first must be a multiple of 32 columns (one LDS stage)");
   if (a.Ka < a.K && (!a.A2 || !a.EA2 || (a.lda2 & 15) || (a.a2_col0 & 15) || a.a2_col0 + (a.K - a.Ka) > a.lda2)) return bad("second A segment");
   if ((a.w_row0 & 31) || (a.w_k0 & 15) || a.w_rb32 <= 0) return bad("weight operand must start on a 32-row / 16-k unit");
   if ((size_t)128 * (a.lda > a.lda2 ? a.lda : a.lda2) * 4 >= 0x7FFFFFFFull) return bad("leading dimension too large");

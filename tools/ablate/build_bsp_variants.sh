@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-pass
 build() {  # name, macros...
   name=$1; shift
   /opt/rocm/bin/hipcc $FLAGS "$@" -c bsp_gemm.hip -o /tmp/bsp_gemm_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsnerf_hip_$name.so gemm.o gemm_x6.o /tmp/bsp_gemm_$name.o bsp_aux.o aux_kernels.o composite.o loss.o optim.o api.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsnerf_hip_$name.so gemm.o gemm_x6.o /tmp/bsp_gemm_$name.o bsp_aux.o bsp_pass.o aux_kernels.o composite.o loss.o optim.o api.o
 }
 build o_noepi -DBSP_ABL_ONEWG -DBSP_ABL_NOEPI &
 build o_mfmaonly -DBSP_ABL_ONEWG -DBSP_ABL_NOEPI -DBSP_ABL_NOLDSREAD -DBSP_ABL_NODMA -DBSP_ABL_NOBLOAD &
