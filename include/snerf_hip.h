@@ -256,11 +256,11 @@ int snerf_adam_step(float* params, const float* grads, float* exp_avg, float* ex
  * Between snerf_profile_begin and snerf_profile_end every GEMM launch is bracketed by HIP events on the
  * stream it is launched on; _end synchronises those events and returns, per kernel variant, the summed
  * device time, the algorithmic FLOPs (2*I*J*K of each launch) and the launch count.
- * variant 0: big-tile GEMMs with both operands K-contiguous (forward X.W^T and dX = dZ.(W^T)^T): gemm_wide_kernel
- *            (128x256 tile) where the width fits, else the 128x128 tile of gemm_x6_kernel,
+ * variant 0: K-contiguous GEMMs (forward X.W^T and dX = dZ.(W^T)^T): gemm_kc_kernel of bsp_gemm.hip in the default
+ *            arithmetic (128x256 tile); the 128x128 tile of gemm_x6_kernel / gemm_kernel under the arithmetic flags,
  *         1: mixed layouts (unused since dX reads a transposed copy of W),
- *         2: both operands row-contiguous (dW = dZ^T.X, split-K; 256x256 or 128x128 tile), 3: the 32-wide head variants.
- * Variants 0-2 run the split kernels of gemm_x6.hip, or gemm_kernel (fp32 MFMA) under SNERF_FLAG_FP32_MFMA. */
+ *         2: dW = dZ^T.X (both operands read along the points, split over the points): gemm_dw_kernel (256x256 tile),
+ *         3: the 32-wide head variants (gemm_kcn_kernel, gemm_dw_kernel<32>). */
 #define SNERF_PROFILE_VARIANTS 4
 typedef struct SnerfProfile {
   double ms[SNERF_PROFILE_VARIANTS];

@@ -250,16 +250,6 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.o_s2 = wtake(Pp * p.H); p.o_s3 = wtake(Pp * p.H);
   p.o_cs2 = keep_c ? wtake(dsize(p.H)) : 0; p.o_cs3 = keep_c ? wtake(dsize(p.H)) : 0;
   p.o_sigo = wtake(Pp * NARROW); p.o_fino = wtake(Pp * NARROW); p.o_suno = wtake(Pp * NARROW);
-  {  // |max| slots (64 uints per tensor) for the operand scaling of the fp16-plane mode
-    int n = 0;
-    p.s_pe = n++; p.s_fa = n++; p.s_h1 = n++; p.s_s2 = n++; p.s_s3 = n++;
-    for (int i = 0; i < p.L; ++i) p.s_h[i] = n++;
-    p.n_fwd_slots = n;
-    p.s_dfin = n++; p.s_dsig = n++; p.s_dsun = n++; p.s_dz1 = n++; p.s_dsa = n++; p.s_dsb = n++; p.s_dfa = n++;
-    for (int i = 0; i <= p.L; ++i) p.s_dz[i] = n++;
-    p.n_slots = n;
-    p.o_amax = wtake((size_t)n * 64);
-  }
   p.maxw = p.W > p.FA ? p.W : p.FA;
   if (p.h1w > p.maxw) p.maxw = p.h1w;
   p.nrb = (p.P + 31) / 32;
@@ -371,20 +361,13 @@ struct WS {
 
 // Weight operand of a K-contiguous GEMM: B = rows [row0, ...) and k >= k0 of the packed matrix at float offset `mat`
 // ([rows][ld]); attach the matrix's pre-split, k-tile-major bf16 planes (same element range in the plane region).
-// |max| slots of a weight matrix in the fp16-plane mode: the packed buffer's third plane region is free (two planes),
-// matrix at float offset `mat` keeps its 64 slots at uint index mat / 2 of that region (matrices are >= 128 floats apart)
-static inline const unsigned* weight_slots(const Plan& p, const float* pk, size_t mat) {
-  return reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(pk + p.n_fp32) + 2 * p.n_fp32) + mat / 2;
-}
-static inline unsigned* slot(const Plan& p, const WS& ws, int id) { return p.fmt == 1 ? ws.u(p.o_amax) + (size_t)id * 64 : nullptr; }
 
 static inline void weights(GemmArgs& g, const Plan& p, const float* pk, size_t mat, int rows, int ld, int row0 = 0, int k0 = 0) {
   g.B = pk + mat + (size_t)row0 * ld + k0; g.ldb = ld;
-  g.x6 = p.x6; g.planes = p.planes; g.fmt = p.fmt;
+  g.x6 = p.x6; g.planes = p.planes;
   if (p.x6) {
     g.Bpl = reinterpret_cast<const unsigned short*>(pk + p.n_fp32) + mat; g.pl_stride = p.n_fp32;
     g.bt_rows = rows; g.bt_row0 = row0; g.bt_k0 = k0; g.bt_elems = (size_t)rows * ld;
-    if (p.fmt == 1) g.b_max = weight_slots(p, pk, mat);
   }
 }
 
@@ -407,21 +390,16 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
   ea.N = p.N; ea.S = p.S; ea.F = p.F; ea.Ep = p.Ep; ea.pe = ws.f(p.o_pe);
   ea.fa = ws.f(p.o_fa); ea.FA = p.FA; ea.W = p.Wf; ea.Xp = p.Xp; ea.x_sun = p.x_sun; ea.x_t = p.x_t; ea.x_ts = p.x_ts; ea.tau = p.tau;
   RC(launch_encode(ea, st));
-  if (p.fmt == 1) {  // operand maxima of the tensors the encode kernel wrote (GEMM epilogues add their own)
-    SNERF_HIP_CHECK(hipMemsetAsync(ws.u(p.o_amax), 0, (size_t)p.n_fwd_slots * 64 * sizeof(unsigned), st));
-    RC(launch_absmax(ws.f(p.o_pe), P, p.Ep, p.Ep, slot(p, ws, p.s_pe), st));
-    RC(launch_absmax(ws.f(p.o_fa) + W, P, p.FA - W, p.FA, slot(p, ws, p.s_fa), st));
-  }
   // 3. trunk (rs_semantic.py:325-334)
   const int act = p.siren ? ACT_SIN : ACT_RELU;
   for (int i = 0; i < p.L; ++i) {
     GemmArgs g;
     const bool skip = (p.skip_mask >> i) & 1u;
-    if (i == 0) { g.A = ws.f(p.o_pe); g.lda = p.Ep; g.a_max = slot(p, ws, p.s_pe); }
+    if (i == 0) { g.A = ws.f(p.o_pe); g.lda = p.Ep; }
     else if (skip) { g.A = ws.f(p.o_pe); g.lda = p.Ep; g.Ka = p.Ep; g.A2 = ws.f(p.o_h[i - 1]); g.lda2 = W;
-                     g.a_max = slot(p, ws, p.s_pe); g.a2_max = slot(p, ws, p.s_h[i - 1]); }
-    else { g.A = ws.f(p.o_h[i - 1]); g.lda = W; g.a_max = slot(p, ws, p.s_h[i - 1]); }
-    g.c_max = slot(p, ws, p.s_h[i]);
+                     }
+    else { g.A = ws.f(p.o_h[i - 1]); g.lda = W; }
+   
     weights(g, p, pk, p.w_tr[i], W, p.k_tr[i]);
     g.I = P; g.J = W; g.K = p.k_tr[i];
     g.C = ws.f(p.o_h[i]); g.ldc = W;
@@ -440,7 +418,7 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
     GemmArgs g;
     g.A = hl; g.lda = W; weights(g, p, pk, p.w_fs, W + NARROW, W); g.I = P; g.J = W; g.K = W;
     g.C = ws.f(p.o_fa); g.ldc = p.FA; g.bias = pk + p.b_fs;
-    g.a_max = slot(p, ws, p.s_h[p.L - 1]); g.c_max = slot(p, ws, p.s_fa);
+   
     RC(launch_gemm(g, st));
   }
   {  // first layer of every head in one GEMM (sc pass: sun-visibility block only)
@@ -449,7 +427,7 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
     const size_t r0 = p.sc ? (size_t)p.sun_col : 0;
     weights(g, p, pk, p.w_h1, p.N1, p.FA, (int)r0); g.J = p.h1w;
     g.C = ws.f(p.o_h1); g.ldc = p.h1w; g.bias = pk + p.b_h1 + r0; g.act = act; g.w0 = 1.f;
-    g.a_max = slot(p, ws, p.s_fa); g.c_max = slot(p, ws, p.s_h1);
+   
     if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_c1); else g.C2 = ws.f(p.o_c1); }
     RC(launch_gemm(g, st));
   }
@@ -458,11 +436,11 @@ static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, c
     GemmArgs g;
     g.A = ws.f(p.o_h1) + sun_col; g.lda = p.h1w; weights(g, p, pk, p.w_s2, H, H); g.I = P; g.J = H; g.K = H;
     g.C = ws.f(p.o_s2); g.ldc = H; g.bias = pk + p.b_s2; g.act = act;
-    g.a_max = slot(p, ws, p.s_h1); g.c_max = slot(p, ws, p.s_s2);
+   
     if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_cs2); else g.C2 = ws.f(p.o_cs2); }
     RC(launch_gemm(g, st));
     g.A = ws.f(p.o_s2); g.lda = H; weights(g, p, pk, p.w_s3, H, H); g.bias = pk + p.b_s3; g.C = ws.f(p.o_s3);
-    g.a_max = slot(p, ws, p.s_s2); g.c_max = slot(p, ws, p.s_s3);
+   
     if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_cs3); else g.C2 = ws.f(p.o_cs3); }
     RC(launch_gemm(g, st));
   }
@@ -506,9 +484,8 @@ static DwMat dw_begin(const Plan& p, int rows, int ldw, int cols, bool narrow_ro
   return m;
 }
 static int dw_gemm(const Plan& p, WS ws, const DwMat& m, const float* dz, int lddz, int I, bool narrow_i, const float* X,
-                   int ldx, int J, size_t slab_off, hipStream_t st, int s_dz = -1, int s_x = -1) {
+                   int ldx, int J, size_t slab_off, hipStream_t st) {
   GemmArgs g;
-  if (p.fmt == 1 && !narrow_i) { g.fmt = 1; g.a_max = slot(p, ws, s_dz); g.b_max = slot(p, ws, s_x); }
   g.A = dz; g.lda = lddz; g.a_ic = true; g.B = X; g.ldb = ldx; g.b_ic = true;
   g.I = I; g.J = J; g.K = p.P;
   g.C = ws.f(p.o_slab) + slab_off; g.ldc = m.ldw;
@@ -521,10 +498,10 @@ static int dw_reduce(const Plan& p, WS ws, const DwMat& m, size_t count, float* 
 static int bias_from_colsum(const Plan& p, WS ws, int width, float* gout, hipStream_t st) {
   return reduce_partials(ws.f(p.o_colsum), p.nrb, (size_t)p.maxw, width, ws.f(p.o_colsum2), gout, st);
 }
-// bias gradient of a NARROW-wide pre-activation buffer; the same pass leaves the buffer's |max| in `slots` (fp16-plane mode)
-static int bias_from_narrow(const Plan& p, WS ws, const float* dnar, float* gout, hipStream_t st, unsigned* slots = nullptr) {
+// bias gradient of a NARROW-wide pre-activation buffer
+static int bias_from_narrow(const Plan& p, WS ws, const float* dnar, float* gout, hipStream_t st) {
   const int nb = colsum32_blocks(p.P);
-  RC(launch_colsum32(dnar, p.P, ws.f(p.o_colsum), st, slots));
+  RC(launch_colsum32(dnar, p.P, ws.f(p.o_colsum), st));
   return reduce_partials(ws.f(p.o_colsum), nb, NARROW, NARROW, ws.f(p.o_colsum2), gout, st);
 }
 
@@ -553,11 +530,6 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
   b.g_beta_s = go->beta_semantic; b.g_logits = go->semantic_logits;
   b.d_sigo = dsig; b.d_fino = dfin; b.d_suno = dsun; b.sky_slab = p.sc ? nullptr : ws.f(p.o_skyslab);
   RC(launch_composite_bwd(b, st));
-  if (p.fmt == 1) {
-    SNERF_HIP_CHECK(hipMemsetAsync(slot(p, ws, p.n_fwd_slots), 0, (size_t)(p.n_slots - p.n_fwd_slots) * 64 * sizeof(unsigned), st));
-    // the |max| of dsig / dsun / dfin comes out of their bias-gradient pass (bias_from_narrow), each before its first
-    // scaled consumer
-  }
   if (!p.sc)
     RC(reduce_partials(ws.f(p.o_skyslab), p.comp_blocks * 4, (size_t)p.sky_floats, p.sky_floats, ws.f(p.o_colsum2),
                        gp + p.sky, st));
@@ -569,11 +541,11 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     const DwMat mf = dw_begin(p, NARROW, p.KF, p.KF, true);
     RC(dw_gemm(p, ws, mf, dfin, NARROW, NARROW, true, ws.f(p.o_h1), p.h1w, p.KF, 0, st));
     RC(dw_reduce(p, ws, mf, (size_t)NARROW * p.KF, gp + p.w_fin, st));
-    RC(bias_from_narrow(p, ws, dfin, gp + p.b_fin, st, slot(p, ws, p.s_dfin)));
+    RC(bias_from_narrow(p, ws, dfin, gp + p.b_fin, st));
     GemmArgs g;  // dz1[:, :KF] = (dfin . W_fin) * act'
     g.A = dfin; g.lda = NARROW; weights(g, p, pk, p.t_fin, p.KF, NARROW); g.I = P; g.J = p.KF; g.K = NARROW;
     g.C = dz1; g.ldc = p.h1w; dact(g, p.o_c1, p.o_h1, p.h1w);
-    g.a_max = slot(p, ws, p.s_dfin); g.c_max = slot(p, ws, p.s_dz1);
+   
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));
     RC(bias_from_colsum(p, ws, p.KF, gp + p.b_h1, st));
@@ -583,26 +555,26 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     const DwMat mh = dw_begin(p, H, H, H, false);
     RC(dw_gemm(p, ws, m4, dsun, NARROW, NARROW, true, ws.f(p.o_s3), H, H, 0, st));
     RC(dw_reduce(p, ws, m4, (size_t)NARROW * H, gp + p.w_s4, st));
-    RC(bias_from_narrow(p, ws, dsun, gp + p.b_s4, st, slot(p, ws, p.s_dsun)));
+    RC(bias_from_narrow(p, ws, dsun, gp + p.b_s4, st));
     GemmArgs g;
     g.A = dsun; g.lda = NARROW; weights(g, p, pk, p.t_s4, H, NARROW); g.I = P; g.J = H; g.K = NARROW;
     g.C = ws.f(p.o_dsa); g.ldc = H; dact(g, p.o_cs3, p.o_s3, H);
-    g.a_max = slot(p, ws, p.s_dsun); g.c_max = slot(p, ws, p.s_dsa);
+   
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));  // dz_s3
     RC(bias_from_colsum(p, ws, H, gp + p.b_s3, st));
-    RC(dw_gemm(p, ws, mh, ws.f(p.o_dsa), H, H, false, ws.f(p.o_s2), H, H, 0, st, p.s_dsa, p.s_s2));
+    RC(dw_gemm(p, ws, mh, ws.f(p.o_dsa), H, H, false, ws.f(p.o_s2), H, H, 0, st));
     RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s3, st));
     g.A = ws.f(p.o_dsa); g.lda = H; weights(g, p, pk, p.t_s3, H, H); g.K = H;
     g.C = ws.f(p.o_dsb); dact(g, p.o_cs2, p.o_s2, H);
-    g.a_max = slot(p, ws, p.s_dsa); g.c_max = slot(p, ws, p.s_dsb);
+   
     RC(launch_gemm(g, st));  // dz_s2
     RC(bias_from_colsum(p, ws, H, gp + p.b_s2, st));
-    RC(dw_gemm(p, ws, mh, ws.f(p.o_dsb), H, H, false, ws.f(p.o_h1) + sun_col, p.h1w, H, 0, st, p.s_dsb, p.s_h1));
+    RC(dw_gemm(p, ws, mh, ws.f(p.o_dsb), H, H, false, ws.f(p.o_h1) + sun_col, p.h1w, H, 0, st));
     RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s2, st));
     g.A = ws.f(p.o_dsb); weights(g, p, pk, p.t_s2, H, H);
     g.C = dz1 + sun_col; g.ldc = p.h1w; dact(g, p.o_c1, p.o_h1, p.h1w, sun_col);
-    g.a_max = slot(p, ws, p.s_dsb); g.c_max = slot(p, ws, p.s_dz1);
+   
     RC(launch_gemm(g, st));  // dz1[:, sun block]
     RC(bias_from_colsum(p, ws, H, gp + p.b_h1 + (size_t)p.sun_col, st));
   }
@@ -610,12 +582,12 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
   {  // 3. fused first head layer: dW, then d[feats | extras]
     const size_t r0 = p.sc ? (size_t)p.sun_col : 0;
     const DwMat m1 = dw_begin(p, p.h1w, p.FA, p.FA, false);
-    RC(dw_gemm(p, ws, m1, dz1, p.h1w, p.h1w, false, ws.f(p.o_fa), p.FA, p.FA, 0, st, p.s_dz1, p.s_fa));
+    RC(dw_gemm(p, ws, m1, dz1, p.h1w, p.h1w, false, ws.f(p.o_fa), p.FA, p.FA, 0, st));
     RC(dw_reduce(p, ws, m1, (size_t)p.h1w * p.FA, gp + p.w_h1 + r0 * p.FA, st));
     GemmArgs g;
     g.A = dz1; g.lda = p.h1w; weights(g, p, pk, p.t_h1, p.FA, p.N1, 0, (int)r0);
     g.I = P; g.J = p.FA; g.K = p.h1w; g.C = dfa; g.ldc = p.FA;
-    g.a_max = slot(p, ws, p.s_dz1); g.c_max = slot(p, ws, p.s_dfa);
+   
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;  // columns [0,W) = bias grad of feats_from_xyz
     RC(launch_gemm(g, st));
     RC(bias_from_colsum(p, ws, W, gp + p.b_fs, st));
@@ -626,15 +598,15 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
   {  // 4. feats + sigma: dW for the [W + NARROW][W] matrix, then dz of the last trunk layer
     const float* hl = ws.f(p.o_h[p.L - 1]);
     const DwMat ms = dw_begin(p, W + NARROW, W, W, false);
-    RC(dw_gemm(p, ws, ms, dfa, p.FA, W, false, hl, W, W, 0, st, p.s_dfa, p.s_h[p.L - 1]));
+    RC(dw_gemm(p, ws, ms, dfa, p.FA, W, false, hl, W, W, 0, st));
     RC(dw_gemm(p, ws, ms, dsig, NARROW, NARROW, true, hl, W, W, (size_t)W * W, st));
     RC(dw_reduce(p, ws, ms, (size_t)(W + NARROW) * W, gp + p.w_fs, st));
-    RC(bias_from_narrow(p, ws, dsig, gp + p.b_fs + W, st, slot(p, ws, p.s_dsig)));
+    RC(bias_from_narrow(p, ws, dsig, gp + p.b_fs + W, st));
     GemmArgs g;
     g.A = dfa; g.lda = p.FA; g.Ka = W; g.A2 = dsig; g.lda2 = NARROW;
     weights(g, p, pk, p.t_fs, W, W + NARROW); g.I = P; g.J = W; g.K = W + NARROW;
     g.C = dz; g.ldc = W; dact(g, p.o_c[p.L - 1], p.o_h[p.L - 1], W, 0, (p.L == 1) ? 30.f : 1.f);
-    g.a_max = slot(p, ws, p.s_dfa); g.a2_max = slot(p, ws, p.s_dsig); g.c_max = slot(p, ws, p.s_dz[p.L - 1]);
+   
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));
     RC(bias_from_colsum(p, ws, W, gp + p.b_tr[p.L - 1], st));
@@ -646,15 +618,15 @@ static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, 
     const bool skip = (p.skip_mask >> i) & 1u;
     const int hoff = (i > 0 && skip) ? p.Ep : 0;  // column of the h part inside W_i
     const DwMat mt = dw_begin(p, W, p.k_tr[i], i == 0 ? p.Ep : W, false);
-    if (i == 0 || skip) RC(dw_gemm(p, ws, mt, dz_cur, W, W, false, ws.f(p.o_pe), p.Ep, p.Ep, 0, st, p.s_dz[i], p.s_pe));
-    if (i > 0) RC(dw_gemm(p, ws, mt, dz_cur, W, W, false, ws.f(p.o_h[i - 1]), W, W, hoff, st, p.s_dz[i], p.s_h[i - 1]));
+    if (i == 0 || skip) RC(dw_gemm(p, ws, mt, dz_cur, W, W, false, ws.f(p.o_pe), p.Ep, p.Ep, 0, st));
+    if (i > 0) RC(dw_gemm(p, ws, mt, dz_cur, W, W, false, ws.f(p.o_h[i - 1]), W, W, hoff, st));
     RC(dw_reduce(p, ws, mt, (size_t)W * p.k_tr[i], gp + p.w_tr[i], st));
     if (i == 0) break;
     GemmArgs g;
     g.A = dz_cur; g.lda = W; weights(g, p, pk, p.t_tr[i], W, W);
     g.I = P; g.J = W; g.K = W; g.C = dz_nxt; g.ldc = W;
     dact(g, p.o_c[i - 1], p.o_h[i - 1], W, 0, (i - 1 == 0) ? 30.f : 1.f);
-    g.a_max = slot(p, ws, p.s_dz[i]); g.c_max = slot(p, ws, p.s_dz[i - 1]);
+   
     g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
     RC(launch_gemm(g, st));
     RC(bias_from_colsum(p, ws, W, gp + p.b_tr[i - 1], st));
@@ -741,13 +713,7 @@ int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* p
   RC(launch_transpose(packed + p.w_fin, p.KF, NARROW, p.KF, packed + p.t_fin, NARROW, st));
   // pre-split, k-tile-major bf16 planes of every matrix that is the weight operand of a 128x128 GEMM
   unsigned short* pl0 = reinterpret_cast<unsigned short*>(packed + p.n_fp32);
-  if (p.fmt == 1)  // fp16-plane mode: two planes; the third plane's space holds the matrices' |max| slots
-    SNERF_HIP_CHECK(hipMemsetAsync(pl0 + 2 * p.n_fp32, 0, p.n_fp32 * sizeof(unsigned short), st));
-  auto planes = [&](size_t mat, int rows, int ld) {
-    unsigned* sl = p.fmt == 1 ? const_cast<unsigned*>(weight_slots(p, packed, mat)) : nullptr;
-    if (sl) { const int rc = launch_absmax(packed + mat, rows, ld, ld, sl, st); if (rc) return rc; }
-    return launch_split_planes(packed + mat, rows, ld, pl0 + mat, p.n_fp32, st, p.fmt, sl);
-  };
+  auto planes = [&](size_t mat, int rows, int ld) { return launch_split_planes(packed + mat, rows, ld, pl0 + mat, p.n_fp32, st); };
   for (int i = 0; i < p.L; ++i) RC(planes(p.w_tr[i], p.W, p.k_tr[i]));
   for (int i = 1; i < p.L; ++i) RC(planes(p.t_tr[i], p.W, p.W));
   RC(planes(p.w_fs, p.W + NARROW, p.W)); RC(planes(p.t_fs, p.W, p.W + NARROW));
@@ -815,16 +781,6 @@ int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, 
   g.narrow_j = (narrow & 3) == 1; g.narrow_i = (narrow & 3) == 2; g.x6 = (narrow & 4) != 0;
   g.planes = (narrow & 8) ? 1 : ((narrow & 16) ? 2 : 3);
   g.tile = (narrow & 32) ? 256 : ((narrow & 64) ? 128 : 0);
-  if (narrow & 256) g.pp = 1;
-  if (narrow & 512) g.wide = 0;
-  if (narrow & 128) {  // fp16 two-plane mode: operand maxima into scratch slots first
-    static unsigned* slots = nullptr;
-    if (!slots) SNERF_HIP_CHECK(hipMalloc(&slots, 2 * 64 * sizeof(unsigned)));
-    SNERF_HIP_CHECK(hipMemsetAsync(slots, 0, 2 * 64 * sizeof(unsigned), (hipStream_t)stream));
-    RC(launch_absmax(A, a_ic ? K : I, a_ic ? I : K, lda, slots, (hipStream_t)stream));
-    RC(launch_absmax(B, b_ic ? K : J, b_ic ? J : K, ldb, slots + 64, (hipStream_t)stream));
-    g.fmt = 1; g.planes = 2; g.x6 = true; g.a_max = slots; g.b_max = slots + 64;
-  }
   return launch_gemm(g, (hipStream_t)stream);
 }
 

@@ -26,14 +26,12 @@ int launch_sample_z(const float* rays, const float* zsteps, const float* u, floa
 int launch_encode(const EncodeArgs& a, hipStream_t st);
 int launch_copy_table(const CopyTable& tb, float* packed, int mode, hipStream_t st);
 int launch_transpose(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t st);
-int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes, size_t plane_stride, hipStream_t st,
-                        int fmt = 0, const unsigned* slots = nullptr);
-int launch_absmax(const float* x, int rows, int cols, int ld, unsigned* slots, hipStream_t st);
+int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes, size_t plane_stride, hipStream_t st);
 int launch_reduce_rows(const float* in, int n_in, size_t in_stride, int width, float* out, size_t out_stride,
                        int group, int accumulate, hipStream_t st);
 int reduce_partials(const float* in, int n_in, size_t in_stride, int width, float* tmp, float* out, hipStream_t st);
 int colsum32_blocks(int rows);   // partial rows launch_colsum32 writes
-int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st, unsigned* slots = nullptr);
+int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st);
 int launch_ray_sum(const float* dfa, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st);
 
 }  // namespace snerf

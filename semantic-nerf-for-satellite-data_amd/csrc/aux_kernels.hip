@@ -153,37 +153,13 @@ int launch_transpose(const float* src, int ld_src, int rows, int cols, float* ds
 // running residual: x = hi + mid + lo to 2^-26 relative), stored k-tile-major [ld/16][rows][16] with the LDS image's
 // swizzle baked in (the two 8-k halves of a row swap on rows with bit 3 set): a 128-row x 16-k tile is then 4 KB
 // of contiguous memory that the GEMM copies to LDS verbatim.  Plane p at planes + p*plane_stride.
-// fmt 1: two fp16 planes of x * scale, scale = the power of two that scale_of_max() derives from the matrix's |max|
-// slots (the GEMM derives the same scale from the same slots and divides it out of the accumulator).
-__device__ __forceinline__ float scale_of_slots(const unsigned* __restrict__ slots) {
-  unsigned m = 0u;
-  for (int i = 0; i < 64; ++i) { const unsigned q = slots[i]; m = q > m ? q : m; }
-  if (m == 0u || m >= 0x7f800000u) return 1.f;
-  int se = 13 - ((int)(m >> 23) - 127);
-  se = se < -60 ? -60 : (se > 60 ? 60 : se);
-  return __uint_as_float((unsigned)(127 + se) << 23);
-}
-
 __global__ void split_planes_kernel(const float* __restrict__ x, int rows, int ld, unsigned short* __restrict__ planes,
-                                    size_t plane_stride, int fmt, const unsigned* __restrict__ slots) {
-  __shared__ float s_scale;
-  if (fmt == 1) {
-    if (threadIdx.x == 0) s_scale = scale_of_slots(slots);
-    __syncthreads();
-  }
+                                    size_t plane_stride) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)rows * ld) return;
   const int r = (int)(i / ld), k = (int)(i - (size_t)r * ld);
   const int kk = k & 15;
   const size_t o = ((size_t)(k >> 4) * rows + r) * 16 + ((((kk >> 3) ^ (r >> 3)) & 1) << 3) + (kk & 7);
-  if (fmt == 1) {
-    const float v = x[i] * s_scale;
-    const _Float16 h = (_Float16)v;
-    const _Float16 l = (_Float16)(v - (float)h);
-    planes[o] = __builtin_bit_cast(unsigned short, h);
-    planes[plane_stride + o] = __builtin_bit_cast(unsigned short, l);
-    return;
-  }
   const float v = x[i];
   const __bf16 h = (__bf16)v;
   const float r1 = v - (float)h;
@@ -194,53 +170,9 @@ __global__ void split_planes_kernel(const float* __restrict__ x, int rows, int l
   planes[2 * plane_stride + o] = __builtin_bit_cast(unsigned short, l);
 }
 
-int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes, size_t plane_stride, hipStream_t st,
-                        int fmt, const unsigned* slots) {
+int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes, size_t plane_stride, hipStream_t st) {
   const size_t n = (size_t)rows * ld;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, rows, ld, planes, plane_stride,
-                     fmt, slots);
-  SNERF_LAUNCH_CHECK();
-  return 0;
-}
-
-// |max| of a rows x cols block (leading dimension ld) into 64 slots of float bits (atomicMax; order-independent, so
-// deterministic).  Slots must have been zeroed.  Used for tensors whose producer is not a GEMM epilogue.
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, int rows, int cols, int ld, unsigned* __restrict__ slots,
-                                                     int vec4) {
-  __shared__ float part[4];
-  float m = 0.f;
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  if (vec4) {   // contiguous and 16-byte aligned: float4 loads
-    const size_t n4 = (size_t)rows * cols / 4;
-    const float4* x4 = reinterpret_cast<const float4*>(x);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-      const float4 v = x4[i];
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-  } else {
-    const size_t n = (size_t)rows * cols;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-      const size_t r = i / cols;
-      m = fmaxf(m, fabsf(x[r * ld + (i - r * cols)]));
-    }
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {   // one atomic per workgroup
-    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-    if (m > 0.f) atomicMax(slots + (blockIdx.x & 63), __float_as_uint(m));
-  }
-}
-
-int launch_absmax(const float* x, int rows, int cols, int ld, unsigned* slots, hipStream_t st) {
-  const size_t n = (size_t)rows * cols;
-  if (n == 0) return 0;
-  const int vec4 = (cols == ld && (cols & 3) == 0 && ((uintptr_t)x & 15) == 0) ? 1 : 0;
-  const size_t want = (n + 8191) / 8192;   // >= 32 elements per thread
-  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(want < 1024 ? (want ? want : 1) : 1024)), dim3(256), 0, st, x, rows, cols, ld,
-                     slots, vec4);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, rows, ld, planes, plane_stride);
   SNERF_LAUNCH_CHECK();
   return 0;
 }
@@ -288,32 +220,22 @@ int reduce_partials(const float* in, int n_in, size_t in_stride, int width, floa
   return launch_reduce_rows(tmp, ng, (size_t)width, width, out, 0, ng, 1, st);
 }
 
-// column sums of a [rows][32] buffer -> partial[blocks][32] (256 rows per block, float4 loads: 8 lanes per row), and
-// optionally the buffer's |max| into 64 slots (the same pass serves the bias gradient and the operand scale)
+// column sums of a [rows][32] buffer -> partial[blocks][32] (256 rows per block, float4 loads: 8 lanes per row)
 constexpr int CS32_ROWS = 256;
-__global__ __launch_bounds__(256) void colsum32_kernel(const float* __restrict__ in, int rows, float* __restrict__ partial,
-                                                       unsigned* __restrict__ slots) {
+__global__ __launch_bounds__(256) void colsum32_kernel(const float* __restrict__ in, int rows, float* __restrict__ partial) {
   __shared__ float4 sm[32][8];
-  __shared__ float smax[4];
   const int c4 = threadIdx.x & 7, rg = threadIdx.x >> 3;   // 32 row groups x 8 column quads
   const int r0 = blockIdx.x * CS32_ROWS;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  float m = 0.f;
 #pragma unroll
   for (int i = 0; i < CS32_ROWS / 32; ++i) {
     const int r = r0 + rg + 32 * i;
     if (r < rows) {
       const float4 v = *reinterpret_cast<const float4*>(in + (size_t)r * 32 + 4 * c4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
   }
   sm[rg][c4] = s;
-  if (slots != nullptr) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
-  }
   __syncthreads();
   if (threadIdx.x < 8) {   // fixed summation order over the 32 row groups
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -321,16 +243,12 @@ __global__ __launch_bounds__(256) void colsum32_kernel(const float* __restrict__
     for (int i = 0; i < 32; ++i) { const float4 v = sm[i][threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
     *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * 32 + 4 * threadIdx.x) = t;
   }
-  if (slots != nullptr && threadIdx.x == 0) {
-    m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-    if (m > 0.f) atomicMax(slots + (blockIdx.x & 63), __float_as_uint(m));
-  }
 }
 
 int colsum32_blocks(int rows) { return (rows + CS32_ROWS - 1) / CS32_ROWS; }
 
-int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st, unsigned* slots) {
-  hipLaunchKernelGGL(colsum32_kernel, dim3(colsum32_blocks(rows)), dim3(256), 0, st, in, rows, partial, slots);
+int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st) {
+  hipLaunchKernelGGL(colsum32_kernel, dim3(colsum32_blocks(rows)), dim3(256), 0, st, in, rows, partial);
   SNERF_LAUNCH_CHECK();
   return 0;
 }

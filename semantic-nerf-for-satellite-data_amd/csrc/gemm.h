@@ -46,15 +46,6 @@ struct GemmArgs {
   // Bpl = plane 0 of the matrix, plane p at Bpl + p*pl_stride elements; the operand is rows [bt_row0, +J) and
   // k >= bt_k0 of a matrix with bt_rows rows.
   const unsigned short* Bpl = nullptr; size_t pl_stride = 0; int bt_rows = 0, bt_row0 = 0, bt_k0 = 0; size_t bt_elems = 0;
-  // fmt = 1 (split kernel only, planes = 2): fp16 planes with power-of-two operand scaling.  Each operand's scale comes
-  // from its |max| (64 device-resident slots of float bits, maxed together; nullptr = scale 1) so that max * scale lies
-  // in [2^13, 2^14); the accumulator is multiplied by 1 / (scale_A * scale_B) (exact).  c_max (optional, any kernel):
-  // the epilogue atomically maxes |stored C| into slot (blockIdx.x & 63) -- the a_max of the launch that consumes C.
-  int fmt = 0;
-  const unsigned* a_max = nullptr; const unsigned* a2_max = nullptr; const unsigned* b_max = nullptr;
-  unsigned* c_max = nullptr;
-  int wide = -1;          // K-contiguous, fmt 1, pre-split B: 1 = 128 x 256 tile, 0 = square tile, -1 = choose
-  int pp = -1;            // 256 tile, fmt 1: 1 = ping-pong schedule, 0 = lockstep, -1 = default (lockstep; SNERF_X6_PP=1 overrides)
   int tile = 0;           // split kernel tile: 128, 256, or 0 = choose (256 when it wastes no more area than 128)
   int planes = 3;         // bf16 planes per operand of the split kernel: 3 fp32-class, 2 ~16-bit, 1 plain bf16
   bool x6 = false;        // split-bf16 MFMA (gemm_x6.hip) for the 128x128 tile when both operands share a layout

@@ -23,8 +23,7 @@
 
 namespace snerf {
 
-void launch_wide(const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip: 128 x 256 tile, fp16 planes, pre-split B
-void launch_x6(bool ic, bool b_planes, int planes, int fmt, int tile, int pp, const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip
+void launch_x6(bool ic, bool b_planes, int planes, int tile, const KArgs& p, dim3 grid, hipStream_t stream);  // gemm_x6.hip
 
 template <int BI, bool IC>
 struct Tile {
@@ -245,7 +244,6 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
   p.sign_groups = ((g.aux_sign ? g.ldaux : g.ldc) + 63) / 64;
   static const unsigned epi_mask = getenv("SNERF_FAST_EPI") ? (unsigned)atoi(getenv("SNERF_FAST_EPI")) : 31u;  // all kinds; env for A/B of single kinds (bit 0 plain, 1 sin, 2 relu, 3 sinrec, 4 relu mask)
   p.epi_mask = epi_mask;
-  p.amaxA = g.a_max; p.amaxA2 = g.A2 ? g.a2_max : nullptr; p.amaxB = g.b_max; p.cmax = g.c_max;
   p.lda = g.lda; p.lda2 = g.A2 ? g.lda2 : g.lda; p.Ka = g.A2 ? g.Ka : 0x7fffffff;
   p.ldb = g.ldb; p.I = g.I; p.J = g.J; p.K = g.K; p.ldc = g.ldc; p.ldaux = g.ldaux; p.ldcs = g.ldcs;
   // operand extents for the buffer descriptors (bytes; checked < 4 GiB by launch_gemm)
@@ -272,16 +270,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
       p.tiles_i = (g.I + 255) / 256; p.tiles_j = (g.J + 255) / 256;
       grid.x = p.tiles_i * p.tiles_j;
     }
-    // K-contiguous launches of the default arithmetic with pre-split weights: 128 x 256 tile when the column padding
-    // is no worse than with 128-wide tiles (J = 256, 512, 1024 ...); SNERF_X6_WIDE=0 keeps the square tile (A/B)
-    static const bool wide_on = !(getenv("SNERF_X6_WIDE") && atoi(getenv("SNERF_X6_WIDE")) == 0);
-    const bool wide_fit = ((g.J + 255) / 256) * 256 == ((g.J + 127) / 128) * 128;
-    if (!A_IC && !B_IC && g.fmt == 1 && g.Bpl != nullptr && tile == 128 && g.k_split == 0 && (g.wide > 0 || (g.wide < 0 && wide_on && wide_fit))) {
-      p.tiles_j = (g.J + 255) / 256;
-      grid.x = p.tiles_i * p.tiles_j;
-      launch_wide(p, grid, stream);
-    } else
-    launch_x6(A_IC, g.Bpl != nullptr && !A_IC, g.planes, g.fmt, tile, g.pp, p, grid, stream);
+    launch_x6(A_IC, g.Bpl != nullptr && !A_IC, g.planes, tile, p, grid, stream);
   }
   else hipLaunchKernelGGL((gemm_kernel<BI, BJ, WI, WJ, A_IC, B_IC>), grid, dim3(NT), 0, stream, p);
   SNERF_LAUNCH_CHECK();
@@ -360,7 +349,6 @@ int launch_gemm(const GemmArgs& g, hipStream_t stream) {
   if (g.Bpl && ((g.bt_k0 & 15) || ((uintptr_t)g.Bpl & 15) || (g.pl_stride & 7) || g.bt_rows <= 0 || g.pl_stride * 6 >= 0xFFFFFFF0ull))
     return bad("pre-split B planes need bt_k0 % 16 == 0 and 16-byte alignment");
   if (g.aux && g.aux_mode != AUX_NONE && g.ldaux <= 0) return bad("aux needs ldaux");
-  if (g.fmt == 1 && (!g.x6 || g.planes != 2)) return bad("fmt 1 (fp16 planes) is the two-plane split kernel");
   if (g.C2s && (g.narrow_j || g.act != ACT_SIN || g.aux_sign)) return bad("C2s (sign words) needs the 64-wide epilogue, ACT_SIN and no AUX_SINREC");
   if (g.aux_mode == AUX_SINREC && (!g.aux || !g.aux_sign || g.narrow_j || (g.sign_col0 & 3))) return bad("AUX_SINREC needs aux, aux_sign, sign_col0 % 4 == 0 and the 64-wide epilogue");
 

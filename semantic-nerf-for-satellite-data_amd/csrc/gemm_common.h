@@ -26,7 +26,6 @@ struct KArgs {
   float* C; float* C2;
   const float* bias; const float* aux; float* colsum;
   unsigned* C2s; const unsigned* auxs; int sign_col0, sign_groups;
-  const unsigned* amaxA; const unsigned* amaxA2; const unsigned* amaxB; unsigned* cmax;
   unsigned epi_mask;   // which (act, aux) kinds take the straight-line epilogue: bit 0 plain, 1 sin, 2 relu, 3 sinrec, 4 relu mask
   unsigned bytesA, bytesA2, bytesB;
   const unsigned short* Bpl; unsigned pl_stride_bytes; unsigned bytesBpl; int bt_rows, bt_row0, bt_k0;
@@ -46,24 +45,6 @@ __device__ __forceinline__ size_t uniform_sz(size_t v) {
 // |cos| from the stored sine: hardware square root (1 ulp) of the once-rounded 1 - h^2; sqrtf() would expand into the
 // ~15-instruction correctly rounded sequence, four times per lane and pass
 __device__ __forceinline__ float cos_from_sin(float h) { return __builtin_amdgcn_sqrtf(fmaxf(fmaf(-h, h, 1.f), 0.f)); }
-
-// ---- operand scaling of the fp16-plane mode --------------------------------------------------------------------
-constexpr int MAX_SLOTS = 64;   // |max| of a tensor = max over 64 slots of float bits (spreads the atomics)
-// power of two s with max * s in [2^13, 2^14) (fp16 overflows at 2^16), clamped to 2^+-60; 1 for an empty / non-finite max
-__device__ __forceinline__ float scale_of_max(unsigned maxbits) {
-  if (maxbits == 0u || maxbits >= 0x7f800000u) return 1.f;
-  int se = 13 - ((int)(maxbits >> 23) - 127);
-  se = se < -60 ? -60 : (se > 60 ? 60 : se);
-  return __uint_as_float((unsigned)(127 + se) << 23);
-}
-// wave-uniform max of one or two slot arrays (nullptr = none)
-__device__ __forceinline__ unsigned slots_max(const unsigned* s1, const unsigned* s2, int lane) {
-  unsigned m = s1 ? s1[lane] : 0u;
-  if (s2) { const unsigned m2 = s2[lane]; m = m2 > m ? m2 : m; }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) { const unsigned q = __shfl_xor(m, o, 64); m = q > m ? q : m; }
-  return m;
-}
 
 // Workgroup -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), and the J-tiles of
 // one I-tile re-read the same A rows, so give each XCD group runs of consecutive J-tiles of the
@@ -172,7 +153,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
   const int rrow = lane / LPR, c4 = 4 * (lane % LPR);
   const int col = j0 + wj0 + c4;
   const bool col_ok = col < p.J;     // J % 4 == 0 (host check): a float4 is entirely inside or outside
-  float vmax = 0.f;  // |max| of what this wave stores (p.cmax)
   float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias != nullptr && col_ok) bj = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll
@@ -243,7 +223,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
           *reinterpret_cast<float4*>(C + off) = v;
 #endif
           cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
-          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
       }
       if (WJ == 64 && p.C2s != nullptr && col_ok) p.C2s[sidx] = sbits;
@@ -259,11 +238,6 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[MI][NJ], float
       }
 #endif
     }
-  }
-  if (p.cmax != nullptr) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-    if (lane == 0 && vmax > 0.f) atomicMax(p.cmax + (blockIdx.x & (MAX_SLOTS - 1)), __float_as_uint(vmax));
   }
 }
 
@@ -299,7 +273,6 @@ __device__ __forceinline__ void gemm_epilogue_fast(const f32x16 (&acc)[MI][NJ], 
   if (p.bias != nullptr && col_ok) bj = *reinterpret_cast<const float4*>(p.bias + col);
   const bool signs_out = ACT == ACT_SIN && p.C2s != nullptr;
   const srd_t srdS = make_srd(signs_out ? p.C2s : nullptr, signs_out ? 0xFFFFFFE0u : 0u);
-  float vmax = 0.f;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int rbase = row0 + 32 * mi;
@@ -349,8 +322,6 @@ __device__ __forceinline__ void gemm_epilogue_fast(const f32x16 (&acc)[MI][NJ], 
         if (!ok) w = make_float4(0.f, 0.f, 0.f, 0.f);
         cs.x += w.x; cs.y += w.y; cs.z += w.z; cs.w += w.w;
       }
-      const float m4 = fmaxf(fmaxf(fabsf(w.x), fabsf(w.y)), fmaxf(fabsf(w.z), fabsf(w.w)));
-      vmax = fmaxf(vmax, ok ? m4 : 0.f);
       buf_store4(srdC, ok ? ((unsigned)(32 * mi + rrow + RPP * ps) * (unsigned)p.ldc + (unsigned)c4) * 4u : OOB, w);
     }
     if (signs_out) __builtin_amdgcn_raw_buffer_store_b32(sbits, srdS, (col_ok && rbase < p.I) ? (unsigned)(sidx * 4) : OOB, 0, 0);
@@ -362,11 +333,6 @@ __device__ __forceinline__ void gemm_epilogue_fast(const f32x16 (&acc)[MI][NJ], 
       }
       if (lane < LPR && col_ok && rbase < p.I) *reinterpret_cast<float4*>(p.colsum + (size_t)(rbase >> 5) * p.ldcs + col) = cs;
     }
-  }
-  if (p.cmax != nullptr) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-    if (lane == 0 && vmax > 0.f) atomicMax(p.cmax + (blockIdx.x & (MAX_SLOTS - 1)), __float_as_uint(vmax));
   }
 }
 

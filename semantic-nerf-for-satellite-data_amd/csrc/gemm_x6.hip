@@ -1,13 +1,12 @@
 // Split-plane GEMMs for gfx950: fp32 operands, fp32 result, fp32-class accuracy, contraction on the 16-bit matrix cores
-// (v_mfma_f32_32x32x16_{f16,bf16}, 16x the fp32 MFMA rate).  One kernel template, two operand formats:
+// (v_mfma_f32_32x32x16_bf16, 16x the fp32 MFMA rate).  These kernels serve SNERF_FLAG_SPLIT3 and the reduced bf16 modes;
+// the default arithmetic (fp16 planes, block exponents) lives in bsp_gemm.hip.
 //
-//   FMT 1, NP 2 (SNERF_FLAG_F16X2, the DEFAULT arithmetic): every operand element, times its tensor's power-of-two
-//     scale, is split ON THE FLY (in the tile loader, between the global load and the LDS store) into two fp16 planes
-//     hi + lo; a product is hi*hi + hi*lo + lo*hi (three MFMAs), the dropped lo*lo term is 2^-22 relative.
-//   FMT 0, NP 3 (SNERF_FLAG_SPLIT3): three bf16 planes a = hi + mid + lo (each the bf16 rounding of the running
-//     residual; residuals are exact in fp32, so the planes carry 24 significant bits); a product is the six plane
-//     products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- each exact in the fp32 accumulator -- and the dropped
-//     terms are <= 2^-26 |a b|, below fp32's own rounding.  NP 2 / NP 1 of this format are the REDUCED modes.
+//   NP 3 (SNERF_FLAG_SPLIT3): every operand element is split ON THE FLY (in the tile loader, between the global load
+//     and the LDS store) into three bf16 planes a = hi + mid + lo (each the bf16 rounding of the running residual;
+//     residuals are exact in fp32, so the planes carry 24 significant bits); a product is the six plane products
+//     hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid -- each exact in the fp32 accumulator -- and the dropped terms are
+//     <= 2^-26 |a b|, below fp32's own rounding.  NP 2 / NP 1 are the REDUCED modes.
 //
 // LDS images (BK = 16, per plane):
 //   KC source (k contiguous: activations X[M][K], weights W[N][K]): [row][16 k] bf16 = 32-B rows; the MFMA
@@ -57,44 +56,6 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4& hi, bf16x4& mid, 
   }
 }
 
-// FMT 1: 4 fp32 (times the operand's power-of-two scale) -> 2 planes x 4 fp16: hi = fp16(x), lo = fp16(x - hi).
-// 22 significant bits of the scaled value; with hh + hl + lh the dropped lo*lo term is 2^-22 relative -- below the
-// rounding of an fp32 GEMM.  Returned as bf16x4 bit patterns (the LDS image is format-agnostic 16-bit data).
-__device__ __forceinline__ void split2h(const float4 v, float scale, bf16x4& hi, bf16x4& lo) {
-#ifdef SNERF_ABL_NOSPLIT  // diagnostic: (almost) no conversion work, planes not meaningful
-  { typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
-    const u32x2n q = {__float_as_uint(v.x) ^ __float_as_uint(v.y), __float_as_uint(v.z) ^ __float_as_uint(v.w)};
-    hi = __builtin_bit_cast(bf16x4, q); lo = hi; (void)scale; return; }
-#endif
-#ifdef SNERF_ABL_CSPLIT   // plain C form (the compiler spends ~4.5 VALU per element on it)
-  const float x[4] = {v.x * scale, v.y * scale, v.z * scale, v.w * scale};
-  f16x4 h, l;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    h[i] = (_Float16)x[i];
-    l[i] = (_Float16)(x[i] - (float)h[i]);
-  }
-  hi = __builtin_bit_cast(bf16x4, h);
-  lo = __builtin_bit_cast(bf16x4, l);
-#else
-  // two mixed-precision FMAs per element: hi = f16(x * s) and lo = f16(x * s - hi) (one rounding each; x * s is exact),
-  // written straight into the packed halves
-  unsigned h01, h23, l01, l23;
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(v.x), "v"(scale));
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v.y), "v"(scale));
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(v.z), "v"(scale));
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v.w), "v"(scale));
-  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l01) : "v"(v.x), "v"(scale), "v"(h01));
-  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v.y), "v"(scale), "v"(h01));
-  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l23) : "v"(v.z), "v"(scale), "v"(h23));
-  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v.w), "v"(scale), "v"(h23));
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  const u32x2 hh = {h01, h23}, ll = {l01, l23};
-  hi = __builtin_bit_cast(bf16x4, hh);
-  lo = __builtin_bit_cast(bf16x4, ll);
-#endif
-}
-
 // byte offset inside one plane
 __device__ __forceinline__ int kc_off(int row, int k) {  // k multiple of 4
   return row * 32 + ((((k >> 3) ^ (row >> 3)) & 1) << 4) + ((k >> 2) & 1) * 8;
@@ -104,36 +65,20 @@ __device__ __forceinline__ int ic_off(int row, int k) {  // row multiple of 4
   return k * (2 * BT) + ((row ^ (32 * (k & 3))) << 1);
 }
 
-template <bool IC, int NP, int BT, int FMT>
-__device__ __forceinline__ void store_planes(const float4 (&v)[2], char* __restrict__ op, int t, float scale) {
+template <bool IC, int NP, int BT>
+__device__ __forceinline__ void store_planes(const float4 (&v)[2], char* __restrict__ op, int t) {
   using T = TileCfg<BT>;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     int il, kl;
     tile_coord<BT, IC, T::NTH>(t, r, il, kl);
     bf16x4 hi, mid, lo;
-    if (FMT == 1) split2h(v[r], scale, hi, mid);
-    else split3(v[r], hi, mid, lo);
+    split3(v[r], hi, mid, lo);
     const int o = IC ? ic_off<BT>(il, kl) : kc_off(il, kl);
     *reinterpret_cast<bf16x4*>(op + o) = hi;
     if (NP > 1) *reinterpret_cast<bf16x4*>(op + T::PLANE_BYTES + o) = mid;
     if (NP > 2) *reinterpret_cast<bf16x4*>(op + 2 * T::PLANE_BYTES + o) = lo;
   }
-}
-
-// one float4 (the r-th of thread t) of an operand tile -> its planes in the LDS image
-template <bool IC, int NP, int BT, int FMT>
-__device__ __forceinline__ void store_planes_one(const float4 v, int r, char* __restrict__ op, int t, float scale) {
-  using T = TileCfg<BT>;
-  int il, kl;
-  tile_coord<BT, IC, T::NTH>(t, r, il, kl);
-  bf16x4 hi, mid, lo;
-  if (FMT == 1) split2h(v, scale, hi, mid);
-  else split3(v, hi, mid, lo);
-  const int o = IC ? ic_off<BT>(il, kl) : kc_off(il, kl);
-  *reinterpret_cast<bf16x4*>(op + o) = hi;
-  if (NP > 1) *reinterpret_cast<bf16x4*>(op + T::PLANE_BYTES + o) = mid;
-  if (NP > 2) *reinterpret_cast<bf16x4*>(op + 2 * T::PLANE_BYTES + o) = lo;
 }
 
 // MFMA operand fragment of one 32-row block (rows r0 .. r0+31 of the tile) from plane `pl`
@@ -162,16 +107,8 @@ __device__ __forceinline__ bf16x8 load_frag(const char* __restrict__ pl, int r0,
 // (8 k of one row) per plane from global to LDS with no conversion work.
 // NP bf16 planes per operand: 3 = fp32-class (six products, the default); 2 = hi | mid with the three products
 // hh, hm, mh (~16 significant bits); 1 = plain bf16 operands, one product.
-// FMT 1 (NP = 2): fp16 planes, operands scaled by powers of two derived from their |max| slots, products hh + hl + lh.
-// PP (BT = 256 only): ping-pong schedule.  The eight waves form two groups (rows 0-127 / 128-255 of the tile; one wave
-// of each group per SIMD) that run the same four-phase k-tile -- fragment reads + staging | MFMAs of block rows 0-1 |
-// fragment reads + staging + global loads | MFMAs of block rows 2-3 -- one workgroup barrier apart, so while one wave
-// of a SIMD issues its MFMAs back to back at raised priority the other does its LDS and VALU work.  Without it the two
-// waves of a SIMD (same workgroup, same barrier) read, compute and stage in lockstep.  (Measured: no gain over the lockstep
-// schedule -- see launch_x6 -- so it is an option, not the default.)
-template <bool IC, bool BPL, int NP, int BT, int FMT = 0, bool PP = false>
+template <bool IC, bool BPL, int NP, int BT>
 __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6_kernel(const KArgs p) {
-  static_assert(!PP || BT == 256, "ping-pong needs the 8-wave tile");
   using T = TileCfg<BT>;
   constexpr int MI = T::MI, NJ = T::NJ, NTH = T::NTH;
   constexpr int PLANE_BYTES = T::PLANE_BYTES;
@@ -187,12 +124,6 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
 #ifdef SNERF_ABL_CLOCK
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  float sa = 1.f, sb = 1.f;   // operand scales (FMT 1); pre-split weight planes carry sb already
-  if (FMT == 1) {
-    sa = scale_of_max(slots_max(p.amaxA, p.amaxA2, lane));
-    sb = scale_of_max(slots_max(p.amaxB, nullptr, lane));
-  }
-  const float sa_scale = sa, sb_scale = sb;
   __builtin_amdgcn_s_setprio(2);  // non-MFMA phases at raised priority (see gemm.hip)
   int ti, tj;
   int kBeg = 0, kEnd = p.K;
@@ -261,12 +192,12 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
     }
   };
   auto store = [&](const Tile& r, char* stage) {
-    store_planes<IC, NP, BT, FMT>(r.ra, stage, t, sa);
+    store_planes<IC, NP, BT>(r.ra, stage, t);
     if (BPL) {
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x4*>(stage + OPERAND_BYTES + pl * PLANE_BYTES + 16 * t) = r.rbp[pl];
     } else {
-      store_planes<IC, NP, BT, FMT>(r.rb, stage + OPERAND_BYTES, t, sb);
+      store_planes<IC, NP, BT>(r.rb, stage + OPERAND_BYTES, t);
     }
   };
   // One k-tile: MFMAs on LDS stage kt & 1; `r` (tile kt+1, requested a full iteration earlier) is split and stored
@@ -293,15 +224,6 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
     auto block = [&](int mi, int nj) {
       const bf16x8 (&am)[NP] = a[mi & 1];
       f32x16 c = acc[mi][nj];
-      if constexpr (FMT == 1) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, am[0]), al = __builtin_bit_cast(f16x8, am[1]);
-        const f16x8 bh = __builtin_bit_cast(f16x8, b[0][nj]), bl = __builtin_bit_cast(f16x8, b[1][nj]);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
-        acc[mi][nj] = c;
-        return;
-      }
       if constexpr (NP > 2) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], b[1][nj], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], b[2][nj], c, 0, 0, 0);
@@ -358,92 +280,6 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
     __syncthreads();
   };
 
-  // ---- ping-pong k-tile (PP) ------------------------------------------------------------------------------------
-  // LDS ordering: every phase that touches LDS ends with s_waitcnt lgkmcnt(0) before the barrier, so reads and writes
-  // of a phase are complete when any wave passes it.  Tile kt+1 is written (stage (kt+1)&1) in the memory phases of
-  // iteration kt -- the last of them, group 1's second, one barrier before group 0 first reads it; stage kt&1 is
-  // rewritten (tile kt+2) from group 0's first memory phase of iteration kt+1, one barrier after group 1's last read.
-  auto pp_barrier_mem = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto pp_barrier = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto ktile_pp = [&](int kt, Tile& r) {
-    const char* sa = lds + (kt & 1) * STAGE_BYTES;
-    const char* sb = sa + OPERAND_BYTES;
-    char* dst = lds + ((kt + 1) & 1) * STAGE_BYTES;
-    bf16x8 b[NP][NJ], a[2][NP];
-    auto block = [&](int mi, int nj) {
-      const bf16x8 (&am)[NP] = a[mi & 1];
-      f32x16 c = acc[mi][nj];
-      if constexpr (FMT == 1) {
-        const f16x8 ah = __builtin_bit_cast(f16x8, am[0]), al = __builtin_bit_cast(f16x8, am[1]);
-        const f16x8 bh = __builtin_bit_cast(f16x8, b[0][nj]), bl = __builtin_bit_cast(f16x8, b[1][nj]);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
-      } else {
-        if constexpr (NP > 2) {
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], b[1][nj], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], b[2][nj], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[2], b[0][nj], c, 0, 0, 0);
-        }
-        if constexpr (NP > 1) {
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], b[1][nj], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], b[0][nj], c, 0, 0, 0);
-        }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], b[0][nj], c, 0, 0, 0);
-      }
-      acc[mi][nj] = c;
-    };
-    auto load_a2 = [&](int mi0) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) a[q][pl] = load_frag<IC, BT>(sa + pl * PLANE_BYTES, wi0 + 32 * (mi0 + q), lane);
-    };
-    // -- memory phase 0: B fragments, A fragments of block rows 0-1; first float4 of tile kt+1's A
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) b[pl][nj] = load_frag<IC, BT>(sb + pl * PLANE_BYTES, wj0 + 32 * nj, lane);
-    load_a2(0);
-    store_planes_one<IC, NP, BT, FMT>(r.ra[0], 0, dst, t, sa_scale);
-    pp_barrier_mem();
-    // -- MFMA phase 0
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) block(mi, nj);
-    __builtin_amdgcn_s_setprio(0);
-    pp_barrier();
-    // -- memory phase 1: A fragments of block rows 2-3; rest of tile kt+1; request tile kt+3
-    load_a2(2);
-    store_planes_one<IC, NP, BT, FMT>(r.ra[1], 1, dst, t, sa_scale);
-    if (BPL) {
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) *reinterpret_cast<u32x4*>(dst + OPERAND_BYTES + pl * PLANE_BYTES + 16 * t) = r.rbp[pl];
-    } else {
-      store_planes<IC, NP, BT, FMT>(r.rb, dst + OPERAND_BYTES, t, sb_scale);
-    }
-    fetch(kBeg + (kt + 3) * BK, r);
-    pp_barrier_mem();
-    // -- MFMA phase 1
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mi = 2; mi < 4; ++mi)
-#pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) block(mi, nj);
-    __builtin_amdgcn_s_setprio(0);
-    pp_barrier();
-  };
-
   Tile r0, r1;
   fetch(kBeg, r0);
   store(r0, lds);
@@ -456,19 +292,9 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
 #endif
   __builtin_amdgcn_s_setprio(0);
   // k-tiles in pairs (an odd count runs one extra tile of zeros: fetches beyond kEnd return zeros)
-  if constexpr (PP) {
-    const int grp = wave >> 2;               // 0: tile rows 0-127, 1: rows 128-255 (one wave of each per SIMD)
-    if (grp == 1) pp_barrier();              // group 1 runs one phase behind
-    for (int kt = 0; kt < nkt; kt += 2) {
-      ktile_pp(kt, r0);
-      ktile_pp(kt + 1, r1);
-    }
-    if (grp == 0) pp_barrier();              // same barrier count for both groups
-  } else {
-    for (int kt = 0; kt < nkt; kt += 2) {
-      ktile(kt, r0);
-      ktile(kt + 1, r1);
-    }
+  for (int kt = 0; kt < nkt; kt += 2) {
+    ktile(kt, r0);
+    ktile(kt + 1, r1);
   }
 #ifdef SNERF_ABL_CLOCK
   const unsigned long long clk2 = __builtin_amdgcn_s_memtime();
@@ -479,9 +305,7 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
   { float sum = 0.f; for (int mi = 0; mi < MI; ++mi) for (int nj = 0; nj < NJ; ++nj) for (int r = 0; r < 16; ++r) sum += acc[mi][nj][r];
     if (sum == 12345.678f) C[0] = sum; return; }
 #endif
-  // FMT 1: the power-of-two operand scales are divided out while the accumulators pass through the LDS strip
-  const float inv = FMT == 1 ? 1.f / (sa * sb) : 1.f;   // exact: powers of two, |exponent| <= 120
-  gemm_epilogue_dispatch<MI, NJ, T::WJ>(acc, reinterpret_cast<float*>(lds), wave, lane, i0 + wi0, j0 + wj0, p, C, inv);
+  gemm_epilogue_dispatch<MI, NJ, T::WJ>(acc, reinterpret_cast<float*>(lds), wave, lane, i0 + wi0, j0 + wj0, p, C, 1.f);
 #ifdef SNERF_ABL_CLOCK
   {  // diagnostic build: cycle stamps of this workgroup's phases into the (otherwise unused) colsum buffer
     const unsigned long long clk3 = __builtin_amdgcn_s_memtime();
@@ -496,153 +320,16 @@ __global__ __launch_bounds__(TileCfg<BT>::NTH, TileCfg<BT>::MIN_WG) void gemm_x6
 #endif
 }
 
-// ---- wide tile for the default arithmetic ---------------------------------------------------------------------------
-// 128 x 256 output tile, four waves of 64 x 128 (two workgroups per CU), K-contiguous A split on the fly into two fp16
-// planes, pre-split weight planes for B.  Per MFMA it stages half the A bytes (global loads, split, LDS writes) and reads
-// 25 % fewer fragment bytes than the 128 x 128 tile; the accumulators are kept as two 64-column halves so that each
-// half goes through the unchanged 64-wide epilogue.
-__global__ __launch_bounds__(256, 2) void gemm_wide_kernel(const KArgs p) {
-  constexpr int TI = 128, TJ = 256, MI = 2, NJ = 4, NP = 2;
-  constexpr int PA = TI * BK * 2, PB = TJ * BK * 2;          // bytes of one plane of the A / B tile
-  constexpr int OPA = NP * PA, OPB = NP * PB, STAGE = OPA + OPB;
-  constexpr int EPI_BYTES = epilogue_lds_floats(64, 4) * 4;
-  constexpr int LDS_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
-
-  const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
-  const int wi0 = (wave >> 1) * 64, wj0 = (wave & 1) * 128;
-  const float sa = scale_of_max(slots_max(p.amaxA, p.amaxA2, lane));
-  const float sb = scale_of_max(slots_max(p.amaxB, nullptr, lane));
-  __builtin_amdgcn_s_setprio(2);
-  int ti, tj;
-  tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);
-  const int i0 = ti * TI, j0 = tj * TJ;
-  const int kEnd = p.K;
-  const int nkt = (kEnd + BK - 1) / BK;
-
-  f32x16 acc[2][MI][2];   // [column half][block row][block column inside the half]
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[h][mi][nj][r] = 0.f;
-
-  const int Ka1 = min(p.Ka, p.K);
-  const srd_t srdA = srd_rows(p.A, p.lda, i0, p.I, Ka1);
-  const srd_t srdA2 = srd_rows(p.A2, p.lda2, i0, p.I, p.K - Ka1);
-  Loader<TI, false, 256> la1, la2;
-  la1.init(t, i0, p.I, p.lda);
-  la2.init(t, i0, p.I, p.lda2);
-  const srd_t srdBp = make_srd(p.Bpl, p.bytesBpl);
-  // the B tile of k-tile kt is PB contiguous bytes per plane; thread t moves the 16-byte chunks t and t + 256
-  const unsigned bp_base = ((unsigned)(p.bt_k0 >> 4) * (unsigned)p.bt_rows + (unsigned)(p.bt_row0 + j0)) * 32u + 16u * t;
-  const unsigned bp_step = (unsigned)p.bt_rows * 32u;
-  // rows of the weight matrix past its end (J not a multiple of 256) read whatever follows in the plane region or zeros:
-  // those columns are >= J and never stored
-  struct Tile { float4 ra[2]; u32x4 rbp[NP][2]; };
-  auto fetch = [&](int k0, Tile& r) {
-    const bool s2 = k0 >= p.Ka;
-    const srd_t sA = s2 ? srdA2 : srdA;
-    const unsigned kbA = s2 ? (unsigned)(k0 - p.Ka) * 4u : (unsigned)k0 * 4u;
-    const int kremA = s2 ? kEnd - k0 : min(kEnd, p.Ka) - k0;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const unsigned base = s2 ? la2.base[q] : la1.base[q];
-      r.ra[q] = buf_load4(sA, (base != OOB && la1.kl[q] < kremA) ? base + kbA : OOB);
-    }
-    const unsigned o = (k0 < kEnd) ? bp_base + (unsigned)(k0 >> 4) * bp_step : OOB;
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-        r.rbp[pl][c] = __builtin_amdgcn_raw_buffer_load_b128(srdBp, o == OOB ? OOB : o + pl * p.pl_stride_bytes + c * 4096u, 0, 0);
-  };
-  auto store = [&](const Tile& r, char* stage) {
-    store_planes<false, NP, 128, 1>(r.ra, stage, t, sa);
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) *reinterpret_cast<u32x4*>(stage + OPA + pl * PB + 16 * t + c * 4096) = r.rbp[pl][c];
-  };
-  auto ktile = [&](int kt, Tile& r) {
-    const char* sA = lds + (kt & 1) * STAGE;
-    const char* sB = sA + OPA;
-    char* dst = lds + ((kt + 1) & 1) * STAGE;
-    bf16x8 b[NP][NJ], a[2][NP];
-#pragma unroll
-    for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-      for (int nj = 0; nj < NJ; ++nj) b[pl][nj] = load_frag<false, 128>(sB + pl * PB, wj0 + 32 * nj, lane);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) a[mi][pl] = load_frag<false, 128>(sA + pl * PA, wi0 + 32 * mi, lane);
-    auto block = [&](int mi, int nj) {
-      f32x16 c = acc[nj >> 1][mi][nj & 1];
-      const f16x8 ah = __builtin_bit_cast(f16x8, a[mi][0]), al = __builtin_bit_cast(f16x8, a[mi][1]);
-      const f16x8 bh = __builtin_bit_cast(f16x8, b[0][nj]), bl = __builtin_bit_cast(f16x8, b[1][nj]);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, c, 0, 0, 0);
-      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
-      acc[nj >> 1][mi][nj & 1] = c;
-    };
-    block(0, 0); block(0, 1); block(0, 2); block(0, 3);
-    store(r, dst);
-    block(1, 0); block(1, 1); block(1, 2); block(1, 3);
-    fetch((kt + 3) * BK, r);
-    __syncthreads();
-  };
-
-  Tile r0, r1;
-  fetch(0, r0);
-  store(r0, lds);
-  fetch(BK, r0);
-  fetch(2 * BK, r1);
-  __syncthreads();
-  __builtin_amdgcn_s_setprio(0);
-  for (int kt = 0; kt < nkt; kt += 2) {
-    ktile(kt, r0);
-    ktile(kt + 1, r1);
-  }
-  __builtin_amdgcn_s_setprio(2);
-  if (i0 + wi0 >= p.I) return;
-  const float inv = 1.f / (sa * sb);
-  // two explicit calls (a loop over the halves would make `acc` a dynamically indexed array, i.e. scratch memory)
-  if (j0 + wj0 < p.J)        // wave-uniform
-    gemm_epilogue_dispatch<MI, 2, 64>(acc[0], reinterpret_cast<float*>(lds), wave, lane, i0 + wi0, j0 + wj0, p, p.C, inv);
-  if (j0 + wj0 + 64 < p.J)
-    gemm_epilogue_dispatch<MI, 2, 64>(acc[1], reinterpret_cast<float*>(lds), wave, lane, i0 + wi0, j0 + wj0 + 64, p, p.C, inv);
-}
-
-void launch_wide(const KArgs& p, dim3 grid, hipStream_t stream) {
-  hipLaunchKernelGGL(gemm_wide_kernel, grid, dim3(256), 0, stream, p);
-}
-
-template <int NP, int BT, int FMT = 0, bool PP = false>
+template <int NP, int BT>
 static void launch_np(bool ic, bool b_planes, const KArgs& p, dim3 grid, hipStream_t stream) {
   const dim3 block(TileCfg<BT>::NTH);
-  if (ic) hipLaunchKernelGGL((gemm_x6_kernel<true, false, NP, BT, FMT, PP>), grid, block, 0, stream, p);
-  else if (b_planes) hipLaunchKernelGGL((gemm_x6_kernel<false, true, NP, BT, FMT, PP>), grid, block, 0, stream, p);
-  else hipLaunchKernelGGL((gemm_x6_kernel<false, false, NP, BT, FMT, PP>), grid, block, 0, stream, p);
+  if (ic) hipLaunchKernelGGL((gemm_x6_kernel<true, false, NP, BT>), grid, block, 0, stream, p);
+  else if (b_planes) hipLaunchKernelGGL((gemm_x6_kernel<false, true, NP, BT>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((gemm_x6_kernel<false, false, NP, BT>), grid, block, 0, stream, p);
 }
 
-// tile: 128 or 256 (p.tiles_i / p.tiles_j and the grid must have been computed for it); fmt 1 = fp16 planes (planes = 2)
-void launch_x6(bool ic, bool b_planes, int planes, int fmt, int tile, int pp_arg, const KArgs& p, dim3 grid, hipStream_t stream) {
-  if (fmt == 1) {
-    if (tile == 256) {
-      // measured equal within noise (dW 0.359 vs 0.353 ms, K-contiguous 0.491 vs 0.485 ms): the loop is not bound by the
-      // waves' phase alignment; the lockstep schedule stays the default, SNERF_X6_PP=1 selects the ping-pong one
-      static const bool pp_env = getenv("SNERF_X6_PP") && atoi(getenv("SNERF_X6_PP")) == 1;
-      const bool pp = pp_arg < 0 ? pp_env : pp_arg != 0;
-      if (pp) launch_np<2, 256, 1, true>(ic, b_planes, p, grid, stream);
-      else launch_np<2, 256, 1>(ic, b_planes, p, grid, stream);
-    } else launch_np<2, 128, 1>(ic, b_planes, p, grid, stream);
-    return;
-  }
+// tile: 128 or 256 (p.tiles_i / p.tiles_j and the grid must have been computed for it)
+void launch_x6(bool ic, bool b_planes, int planes, int tile, const KArgs& p, dim3 grid, hipStream_t stream) {
   if (tile == 256) {
     if (planes == 1) launch_np<1, 256>(ic, b_planes, p, grid, stream);
     else if (planes == 2) launch_np<2, 256>(ic, b_planes, p, grid, stream);

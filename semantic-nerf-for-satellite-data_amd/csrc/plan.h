@@ -49,10 +49,7 @@ struct Plan {
   size_t t_fin = 0;  // [KF][NARROW]
   size_t n_fp32 = 0;         // floats of the fp32 region (parameters + transposes); bf16 planes follow it
   size_t packed_floats = 0;  // whole packed buffer in floats: fp32 region + 3 bf16 planes of it
-  int fmt = 0;       // 1: fp16 planes (two, hh + hl + lh) with power-of-two operand scaling from |max| slots (SNERF_FLAG_F16X2 = no arithmetic flag = the default)
-  size_t o_amax = 0; int n_fwd_slots = 0, n_slots = 0;
-  int s_pe = 0, s_fa = 0, s_h1 = 0, s_s2 = 0, s_s3 = 0, s_h[SNERF_MAX_LAYERS] = {0};
-  int s_dfin = 0, s_dsig = 0, s_dsun = 0, s_dz1 = 0, s_dsa = 0, s_dsb = 0, s_dfa = 0, s_dz[SNERF_MAX_LAYERS + 1] = {0};
+  int fmt = 0;       // 1: block-scaled fp16 planes (csrc/bsp.h; no arithmetic flag = the default); 0: fp32 activations (split3 / fp32 / bf16 modes)
   bool sign_deriv = true;  // SIREN derivative kept as sign bits + recomputed from h (false: stored w0*cos floats)
   int planes = 3;    // planes per operand: fmt 1: 2 fp16 (default); fmt 0: 3 bf16 (SNERF_FLAG_SPLIT3), 2 (SNERF_FLAG_BF16X3), 1 (SNERF_FLAG_BF16)
   bool x6 = true;    // split-bf16 MFMA for the 128x128 GEMMs (fp32 MFMA when SNERF_FLAG_FP32_MFMA)
