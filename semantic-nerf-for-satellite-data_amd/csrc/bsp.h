@@ -75,7 +75,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], float scale, u32x4& 
 __device__ __forceinline__ void join8(const u32x4 hi, const u32x4 lo, float inv_scale, float (&x)[8]) {
   const f16x8 h = __builtin_bit_cast(f16x8, hi), l = __builtin_bit_cast(f16x8, lo);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) x[i] = ((float)h[i] + (float)l[i]) * inv_scale;
+  for (int i = 0; i < 8; ++i) x[i] = fmaf((float)h[i], inv_scale, (float)l[i] * inv_scale);   // two v_fma_mix_f32; exact (power of two)
 }
 
 // ---- K-contiguous GEMM:  C[i][j] = epilogue( sum_k A(i,k) W(j,k) ) -------------------------------------------------

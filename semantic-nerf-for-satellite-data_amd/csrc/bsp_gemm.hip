@@ -67,6 +67,61 @@ __device__ __forceinline__ f32x16 mfma3(f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl, 
   return c;
 }
 
+// |max| folded two values at a time (v_max3_f32 with |.| source modifiers; a plain fmaxf chain spends a canonicalising
+// v_max per input under IEEE rules, 2 instructions per value)
+__device__ __forceinline__ float absmax3(float a, float b, float m) {
+  float r;
+  asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+  return r;
+}
+
+// Eight sines sin(v_c) in place + bit c of the returned byte = cos(v_c) < 0.  Same reduction and polynomial as
+// sin4_signcos (common.h) in fewer instructions, for a wave whose epilogue is issue-bound (one instruction per four
+// cycles): k = round(x / pi) comes out of the low mantissa bits of x / pi + 1.5 * 2^23 (no v_rndne / v_cvt), the sign of
+// the sine is bit 0 of k shifted onto the result's sign bit by one v_lshl_add, and the cosine's sign -- (k odd) xor
+// (|r| > pi / 2), the second only at the rounding edge of the reduction -- is the top bit of (k << 31) + bits(pi/2 - |r|),
+// shifted into the byte by v_alignbit.  Arguments beyond 30000 (never with sane data) take sin4_signcos's exact path.
+__device__ __forceinline__ unsigned sin8_signbits(float (&v)[8]) {
+  float (&x)[8] = v;
+  const float m = absmax3(x[6], x[7], absmax3(x[4], x[5], absmax3(x[2], x[3], absmax3(x[0], x[1], 0.f))));
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(m <= 30000.f)) != 0ull, 0)) {
+    unsigned n0, n1;
+    const float4 s0 = sin4_signcos(make_float4(x[0], x[1], x[2], x[3]), &n0);
+    const float4 s1 = sin4_signcos(make_float4(x[4], x[5], x[6], x[7]), &n1);
+    v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
+    return n0 | (n1 << 4);
+  }
+  // arithmetic first, as plain loops the compiler packs two elements per v_pk_fma_f32; the sign work (asm) afterwards
+  float t[8], r[8], sv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) t[c] = fmaf(x[c], 0.31830988618379067154f, 12582912.f);   // low mantissa bits = k
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float kf = t[c] - 12582912.f;
+    float q = fmaf(kf, -3.140625f, x[c]);
+    q = fmaf(kf, -9.67502593994140625e-4f, q);
+    r[c] = fmaf(kf, -1.509958025280866e-07f, q);   // |k| < 2^14: the next term of pi (3.4e-15 k) is below 1e-10
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float r2 = r[c] * r[c];
+    float q = fmaf(r2, -2.5028294103890403e-08f, 2.755689592959243e-06f);
+    q = fmaf(q, r2, -0.00019841265748254955f);
+    q = fmaf(q, r2, 0.008333333767950535f);
+    q = fmaf(q, r2, -0.1666666716337204f);
+    sv[c] = fmaf(r[c] * r2, q, r[c]);
+  }
+  unsigned byte = 0u;
+#pragma unroll
+  for (int c = 7; c >= 0; --c) {
+    const unsigned kb = __float_as_uint(t[c]);
+    v[c] = __uint_as_float((kb << 31) + __float_as_uint(sv[c]));
+    const float edge = 1.57079637f - fabsf(r[c]);
+    byte = __builtin_amdgcn_alignbit(byte, (kb << 31) + __float_as_uint(edge), 31);
+  }
+  return byte;
+}
+
 // exponent of k-step s of a K-contiguous A operand made of one or two segments (any lane; uniform inputs)
 __device__ __forceinline__ int kc_exp_of_step(const KcArgs& p, int rb, int s, int nks1) {
   const bool seg2 = s >= nks1;   // branch-free: one load through a selected pointer
@@ -277,14 +332,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   };
   // The k-loop runs at raised priority: while the SIMD's other wave (the co-resident workgroup) is in its VALU-heavy
   // epilogue, MFMA issue goes first and the epilogue stream fills the 24 of every 32 cycles the matrix pipe leaves free.
-  __builtin_amdgcn_s_setprio(2);
+#ifndef BSP_KC_PRIO_LOOP
+#define BSP_KC_PRIO_LOOP 2
+#define BSP_KC_PRIO_EPI 0
+#endif
+  __builtin_amdgcn_s_setprio(BSP_KC_PRIO_LOOP);
   for (int s = 0; s < 2 * nst; s += 6) {   // an odd count of 16-deep steps runs one sub-step on zero weights
     step(s, 0, 0, bq0, bq2);
     step(s + 1, 0, 1, bq1, bq0);
     if (s + 2 < 2 * nst) { step(s + 2, 1, 0, bq2, bq1); step(s + 3, 1, 1, bq0, bq2); }
     if (s + 4 < 2 * nst) { step(s + 4, 2, 0, bq1, bq0); step(s + 5, 2, 1, bq2, bq1); }
   }
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(BSP_KC_PRIO_EPI);
   wait_vm<0>();        // rejected requests behind the last stage write zeros into the ring: drain before re-using it
   barrier_raw();
 #ifdef BSP_ABL_STAMP
@@ -309,10 +368,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   //      their |max|, column sums; phase B (after the two waves of a 128 x 128 block have exchanged maxima): split + store.
   const int e_in = e_last + *p.EW;          // acc = true value * 2^e_in
   const bool e_small = e_in >= -120 && e_in <= 120;
-  const float inv_in = e_small ? pow2f(-e_in) : 1.f;
+  const float act_w0 = ACT == ACT_SIN ? p.w0 : 1.f;                  // sin(w0 (z + b)) = sin(z (2^-e w0) + b w0)
+  const float inv_in = (e_small ? pow2f(-e_in) : 1.f) * act_w0;
   float* strip = reinterpret_cast<float*>(lds + wave * KC_STRIP);
   const int lc = lane & 31, lh = lane >> 5;
-  const int rrow = lane >> 3, c8 = (lane & 7) * 8;
+  // Row layout of the epilogue: lane -> row (lane >> 3) of an 8-row pass and eight consecutive columns.  The four
+  // 16-column groups of the wave's 64 columns go to the lane pairs in the order 0, 2, 1, 3, so that each quad of lanes
+  // owns groups {m, m + 2}: after one exchange inside the quad (phase B) a store instruction writes WHOLE 64-byte
+  // groups, two neighbouring ones (128 contiguous bytes) per row.
+  const int rrow = lane >> 3, l7 = lane & 7;
+  const int c8 = 16 * ((((l7 >> 1) & 1) << 1) | (l7 >> 2)) + 8 * (l7 & 1);
   const int col = j0 + wj0 + c8;
   const bool col_ok = col < p.J;
   float val[4][4][8];
@@ -326,6 +391,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   if (p.bias != nullptr && col_ok) {
     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
     bj[0] = b0.x; bj[1] = b0.y; bj[2] = b0.z; bj[3] = b0.w; bj[4] = b1.x; bj[5] = b1.y; bj[6] = b1.z; bj[7] = b1.w;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) bj[c] *= act_w0;
   }
   if (!e_small) {   // exponents beyond a single fp32 factor (never with sane data): scale the accumulators first
 #pragma unroll
@@ -357,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + 32 * n + lc] = acc[b][n][r];
     unsigned sbits = 0u;
+    const unsigned swordx = sword ^ (p.w0 < 0.f ? 0xFFFFFFFFu : 0u), w0mag = __float_as_uint(fabsf(p.w0));
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
@@ -366,13 +434,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
       const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       float v[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) v[c] = fmaf(x[c], inv_in, bj[c]);      // exact power of two, then + bias
+      for (int c = 0; c < 8; ++c) v[c] = fmaf(x[c], inv_in, bj[c]);      // exact power of two, then + bias (SIREN: both times w0)
       if (ACT == ACT_SIN) {
-        unsigned n0, n1;
-        const float4 s0 = sin4_signcos(make_float4(p.w0 * v[0], p.w0 * v[1], p.w0 * v[2], p.w0 * v[3]), &n0);
-        const float4 s1 = sin4_signcos(make_float4(p.w0 * v[4], p.w0 * v[5], p.w0 * v[6], p.w0 * v[7]), &n1);
-        v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
-        sbits |= (n0 | (n1 << 4)) << (8 * ps);
+        sbits |= sin8_signbits(v) << (8 * ps);
       } else if (ACT == ACT_RELU) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -381,25 +445,30 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
         float h[8];
         join8(hh[ps], hl[ps], inv_h, h);
         if (AUX == AUX_SINREC) {
-          const unsigned byte = sword >> (8 * ps);
+          // w0 cos(w0 z) = +-|w0| sqrt(1 - h^2): the sign bit (xor-ed with w0's own sign, once per word) is shifted to bit
+          // 31 and merged over |w0| by one v_bfi; 1 - h^2 is clamped at 0 by the FMA's output modifier
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
-            const float d = p.w0 * cos_from_sin(h[c]);
-            v[c] *= ((byte >> c) & 1u) ? -d : d;
+            float om;
+            asm("v_fma_f32 %0, -%1, %1, 1.0 clamp" : "=v"(om) : "v"(h[c]));
+            const unsigned sh = swordx << (31 - (8 * ps + c));
+            const float w0s = __uint_as_float((sh & 0x80000000u) | w0mag);
+            v[c] *= w0s * __builtin_amdgcn_sqrtf(om);
           }
         } else {
 #pragma unroll
           for (int c = 0; c < 8; ++c) v[c] = h[c] > 0.f ? v[c] : 0.f;
         }
       }
+      // rows / columns outside the problem: their stores are rejected by the descriptor; keep them out of the block
+      // maximum and the column sums (their values are finite: zero operand rows through the same arithmetic)
+      const float okf = ok ? 1.f : 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
-        v[c] = ok ? v[c] : 0.f;
-        if (COLSUM) cs[c] += v[c];
+        if (COLSUM) cs[c] = fmaf(v[c], okf, cs[c]);
         val[b][ps][c] = v[c];
       }
-      wmax = fmaxf(wmax, fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))),
-                               fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7])))));
+      wmax = fmaxf(wmax, okf * absmax3(v[6], v[7], absmax3(v[4], v[5], absmax3(v[2], v[3], absmax3(v[0], v[1], 0.f)))));
     }
     if (ACT == ACT_SIN && p.Csign != nullptr && col_ok && rbase < p.I)
       p.Csign[((size_t)(rbase >> 5) * ((p.ldc + 63) >> 6) + ((p.c_col0 + j0 + wj0) >> 6)) * 64 + lane] = sbits;
@@ -415,42 +484,66 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
       }
     }
   }
+#ifdef BSP_ABL_STAMP
+  const unsigned long long se1 = __builtin_amdgcn_s_memtime();
+#endif
   // block maximum: waves 2 c and 2 c + 1 share the exponent block (ti, column block c of the tile)
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
   if (lane == 0) smax[wave] = wmax;
   __syncthreads();
+#ifdef BSP_ABL_STAMP
+  const unsigned long long se2 = __builtin_amdgcn_s_memtime();
+#endif
   const float bmax = fmaxf(smax[wave & 2], smax[(wave & 2) + 1]);
   const int eC = exp_of_maxbits(__float_as_uint(bmax));
   const float sc = pow2f(eC);
   if ((wave & 1) == 0 && lane == 0 && j0 + wj0 < p.J) p.EC[(size_t)ti * ncb_of(p.ldc) + ((p.c_col0 + j0 + wj0) >> 7)] = eC;
   const size_t offC = uniform_sz(((size_t)i0 * p.ldc + p.c_col0) * 4);
   const srd_t srdC = make_srd(p.C + offC, 0xFFFFFFE0u);
+  // quad exchange: lanes 0, 1 of a quad hold group m (hi and lo planes of columns 0-7 / 8-15), lanes 2, 3 group m + 2.
+  // Lanes 0, 1 hand their lo planes to lanes 2, 3 and get those lanes' hi planes; store 1 then writes group m complete
+  // ([hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] = the four lanes' 16 bytes in address order), store 2 group m + 2.
+  const int q4 = lane & 3, mq = l7 >> 2;
+  const bool lowpair = q4 < 2;
+  const bool g1_ok = j0 + wj0 + 16 * mq < p.J, g2_ok = j0 + wj0 + 16 * (mq + 2) < p.J;
+  const unsigned ocol = (unsigned)(((j0 + wj0) >> 4) + mq) * 64u + (unsigned)q4 * 16u;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int rl = 32 * b + rrow + 8 * ps;
-      const bool ok = col_ok && (i0 + rl) < p.I;
-      u32x4 hi, lo;
+      const bool rok = (i0 + rl) < p.I;
+      u32x4 hi, lo, d1, d2;
       split8(val[b][ps], sc, hi, lo);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned send = lowpair ? lo[i] : hi[i];
+        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0x4E, 0xF, 0xF, false);   // quad_perm [2, 3, 0, 1]
+        d1[i] = lowpair ? hi[i] : recv;
+        d2[i] = lowpair ? recv : lo[i];
+      }
 #ifdef BSP_ABL_NOSTORE
-      const unsigned o = (ok && p.I < 0) ? 0u : OOB;
+      const unsigned o = (rok && p.I < 0) ? 0u : OOB;
 #else
-      const unsigned o = ok ? (unsigned)rl * (unsigned)p.ldc * 4u + (unsigned)(col >> 4) * 64u + (unsigned)(col & 8) * 2u : OOB;
+      const unsigned o = rok ? (unsigned)rl * (unsigned)p.ldc * 4u + ocol : OOB;
 #endif
-      __builtin_amdgcn_raw_buffer_store_b128(hi, srdC, o, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(lo, srdC, o == OOB ? OOB : o + 32u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(d1, srdC, (o != OOB && g1_ok) ? o : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(d2, srdC, (o != OOB && g2_ok) ? o + 128u : OOB, 0, 0);
     }
   }
 #ifdef BSP_ABL_STAMP
+  const unsigned long long se3 = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (t == 0 && p.colsum != nullptr) {
+  const unsigned long long se4 = __builtin_amdgcn_s_memtime();
+  if (t == 0 && p.colsum != nullptr) {   // 100 MHz stamps (start, loop end, end) + shader-clock cycles of the phases
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.colsum) + 8 * (size_t)blockIdx.x;
     dbg[0] = st0; dbg[1] = st1; dbg[2] = __builtin_amdgcn_s_memrealtime();
-    dbg[3] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((32 - 1) << 11));       // HW_REG_HW_ID
-    dbg[4] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11));       // HW_REG_XCC_ID
-    dbg[5] = st_vm; dbg[6] = st_wait; dbg[7] = sc1 - sc0;   // shader-clock cycles: in vmcnt waits, in barriers, whole k-loop
+    dbg[3] = sc1 - sc0;                                   // k-loop
+    dbg[4] = (st_vm << 32) | (st_wait & 0xFFFFFFFFull);   // of it: in vmcnt waits | in barriers
+    dbg[5] = se1 - sc1;                                   // epilogue phase A (values, activation, maxima)
+    dbg[6] = se2 - se1;                                   // exchange of the block maxima (workgroup barrier)
+    dbg[7] = ((se3 - se2) << 32) | ((se4 - se3) & 0xFFFFFFFFull);   // split + store issue | store drain
   }
 #endif
 }

@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../../semantic-nerf-for-satellite-data_amd/csrc"
 make -j6 ARCH=gfx950 >/dev/null
 OUT=../../tools/ablate
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-pass-failed"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-pass-failed -fno-slp-vectorize"
 build() {  # name, macros...
   name=$1; shift
   /opt/rocm/bin/hipcc $FLAGS "$@" -c bsp_gemm.hip -o /tmp/bsp_gemm_$name.o
