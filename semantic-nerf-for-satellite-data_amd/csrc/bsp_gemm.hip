@@ -400,25 +400,34 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], -e_in);
   }
+  // stored activations (and sign words) of the derivative epilogues: block b + 1 is requested before block b is worked on
+  constexpr int NH = AUX != AUX_NONE ? 4 : 1;
+  u32x4 hh2[2][NH], hl2[2][NH];
+  unsigned sword2[2] = {0u, 0u};
+  auto load_h = [&](int b, u32x4 (&hh)[NH], u32x4 (&hl)[NH], unsigned& sword) {
+    if (AUX == AUX_NONE) return;
+    const int rbase = i0 + 32 * b;
+#pragma unroll
+    for (int ps = 0; ps < NH; ++ps) {
+      const int rl = 32 * b + rrow + 8 * ps;
+      const bool ok = col_ok && (i0 + rl) < p.I;
+      const unsigned o = ok ? (unsigned)rl * (unsigned)p.ldh * 4u + (unsigned)(col >> 4) * 64u + (unsigned)(col & 8) * 2u : OOB;
+      hh[ps] = __builtin_amdgcn_raw_buffer_load_b128(srdH, o, 0, 0);
+      hl[ps] = __builtin_amdgcn_raw_buffer_load_b128(srdH, o == OOB ? OOB : o + 32u, 0, 0);
+    }
+    if (AUX == AUX_SINREC) {
+      const size_t sidx = ((size_t)(rbase >> 5) * ((p.ldh + 63) >> 6) + ((p.h_col0 + j0 + wj0) >> 6)) * 64 + lane;
+      sword = p.Hsign[(col_ok && rbase < p.I) ? sidx : 0];
+    }
+  };
+  load_h(0, hh2[0], hl2[0], sword2[0]);
 #pragma unroll
   for (int b = 0; b < 4; ++b) {          // 32-row blocks of the wave tile
     const int rbase = i0 + 32 * b;
-    u32x4 hh[AUX != AUX_NONE ? 4 : 1], hl[AUX != AUX_NONE ? 4 : 1];
-    unsigned sword = 0u;
-    if (AUX != AUX_NONE) {
-#pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        const int rl = 32 * b + rrow + 8 * ps;
-        const bool ok = col_ok && (i0 + rl) < p.I;
-        const unsigned o = ok ? (unsigned)rl * (unsigned)p.ldh * 4u + (unsigned)(col >> 4) * 64u + (unsigned)(col & 8) * 2u : OOB;
-        hh[ps] = __builtin_amdgcn_raw_buffer_load_b128(srdH, o, 0, 0);
-        hl[ps] = __builtin_amdgcn_raw_buffer_load_b128(srdH, o == OOB ? OOB : o + 32u, 0, 0);
-      }
-      if (AUX == AUX_SINREC) {
-        const size_t sidx = ((size_t)(rbase >> 5) * ((p.ldh + 63) >> 6) + ((p.h_col0 + j0 + wj0) >> 6)) * 64 + lane;
-        sword = p.Hsign[(col_ok && rbase < p.I) ? sidx : 0];
-      }
-    }
+    if (b + 1 < 4) load_h(b + 1, hh2[(b + 1) & 1], hl2[(b + 1) & 1], sword2[(b + 1) & 1]);
+    u32x4 (&hh)[NH] = hh2[b & 1];
+    u32x4 (&hl)[NH] = hl2[b & 1];
+    const unsigned sword = sword2[b & 1];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -536,8 +545,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   const unsigned long long se3 = __builtin_amdgcn_s_memtime();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long se4 = __builtin_amdgcn_s_memtime();
-  if (t == 0 && p.colsum != nullptr) {   // 100 MHz stamps (start, loop end, end) + shader-clock cycles of the phases
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(p.colsum) + 8 * (size_t)blockIdx.x;
+  // stamp buffer: the (otherwise unused) colsum pointer of a launch without column sums, the sign-word pointer of one with
+  unsigned long long* dbg0 = COLSUM ? reinterpret_cast<unsigned long long*>(p.Csign) : reinterpret_cast<unsigned long long*>(p.colsum);
+  if (t == 0 && dbg0 != nullptr) {   // 100 MHz stamps (start, loop end, end) + shader-clock cycles of the phases
+    unsigned long long* dbg = dbg0 + 8 * (size_t)blockIdx.x;
     dbg[0] = st0; dbg[1] = st1; dbg[2] = __builtin_amdgcn_s_memrealtime();
     dbg[3] = sc1 - sc0;                                   // k-loop
     dbg[4] = (st_vm << 32) | (st_wait & 0xFFFFFFFFull);   // of it: in vmcnt waits | in barriers

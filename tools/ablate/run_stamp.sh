@@ -5,6 +5,6 @@ TAG=$1; shift
 O=gpurun_out/r2b/$TAG; mkdir -p $O
 for v in "$@"; do
   export SNERF_LIB_PATH=$GRAFT_REPO_ROOT/tools/ablate/libsnerf_hip_$v.so STAMP_OUT=$O/$v.npy
-  timeout -k 10 120 python3 tools/bsp_kernel_bench.py 3 stamp > $O/$v.log 2>&1 || { tail $O/$v.log; exit 1; }
+  timeout -k 10 120 python3 tools/bsp_kernel_bench.py 3 ${STAMP_MODE:-stamp} > $O/$v.log 2>&1 || { tail $O/$v.log; exit 1; }
   echo "== $v"; python3 tools/ablate/stamp_summary.py $O/$v.npy
 done

@@ -41,8 +41,12 @@ for _ in range(reps if which in ("plain",) else 0):   # forward layer without ac
     _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), p(b), P, W, W, 0, 0, 0, 1.0, 0, None, None, p(H), None, None, 0, st), "plain")
 G = torch.randn(P, W, generator=g).to(dev) * 1e-3
 D = torch.empty(P, W, device=dev)
-for _ in range(reps if which in ("all", "kc", "dx") else 0):   # dX with the derivative epilogue + bias-gradient column sums
-    _lib.check(L.snerf_test_bsp_kc(p(G), None, W, p(Wm), None, P, W, W, 0, 0, 0, 1.0, 3, p(H), p(sign), p(D), None, p(cs), 0, st), "dx")
+dbg = torch.zeros(8 * 4096, dtype=torch.int64, device=dev) if which == "stampdx" else None
+for _ in range(reps if which in ("all", "kc", "dx", "stampdx") else 0):   # dX with the derivative epilogue + bias-gradient column sums
+    _lib.check(L.snerf_test_bsp_kc(p(G), None, W, p(Wm), None, P, W, W, 0, 0, 0, 1.0, 3, p(H), p(sign), p(D), p(dbg), p(cs), 0, st), "dx")
+if which == "stampdx":
+    import numpy as np
+    np.save(os.environ.get("STAMP_OUT", "gpurun_out/stamps.npy"), dbg.reshape(4096, 8).cpu().numpy())
 Cw = torch.empty(W, W, device=dev)
 for _ in range(reps if which in ("all", "dw") else 0):   # dW, 64 splits
     _lib.check(L.snerf_test_bsp_dw(p(G), W, p(X), W, P, W, W, 0, 0, 4096, 0, p(Cw), st), "dw")
