@@ -256,8 +256,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #ifdef BSP_ABL_STAMP
   unsigned long long st_wait = 0, st_vm = 0;
 #endif
-  // one 16-deep sub-step s = 2 S + u of stage S: MFMAs on (LDS slot, weight registers `bc`); `bn` receives the weight
-  // fragments of sub-step s + 2.  The workgroup barrier comes once per STAGE (u == 0).
+  // One 16-deep sub-step s = 2 S + u of stage S: 24 MFMAs on the fragments `fa` (read from LDS during the PREVIOUS sub-step)
+  // and the weight registers `bc`; `bn` receives the weight fragments of sub-step s + 2.  A single wave issues one
+  // instruction per ~4 cycles, an MFMA occupies the matrix pipe for 32: whatever is issued in a block of its own (the
+  // reads, loads and DMA requests of a sub-step at its top: ~600 cycles, measured with one workgroup per CU: 1490 cycles
+  // per sub-step against 768 of MFMA) leaves the pipe idle, so every non-MFMA instruction sits in a gap between MFMAs:
+  // per 32-row block mi the six MFMAs run hi*lo, lo*hi, hi*hi on two accumulators each, the lo fragment of mi is
+  // re-read for sub-step s + 1 as soon as its last MFMA has been issued, the hi fragment after the block, and the four
+  // weight loads / two DMA pieces are spread over the blocks.  The workgroup barrier of a new stage comes in the middle
+  // of the last sub-step of its predecessor (before the first read of the new stage): every wave has passed the
+  // top-of-sub-step wait that covers its own pieces of stage S + 1 (issued during stage S - 1) and has finished reading
+  // stage S - 1, whose slot the requests of stage S + 2 (issued after that point in program order) overwrite.
+  struct AFrag { f16x8 h[4], l[4]; };
+  AFrag fa;
+  auto loadB2 = [&](int s, BFrag& b, int half) {     // two of the four weight loads of sub-step s
+    const unsigned so = s < nks ? ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_u0) * 2048u : OOB;
+    if (half == 0) {
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(b.h[0]) : "v"(voW), "s"(srdW), "s"(so));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(b.l[0]) : "v"(voW), "s"(srdW), "s"(so));
+    } else {
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:2048" : "=v"(b.h[1]) : "v"(voW), "s"(srdW), "s"(so));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:3072" : "=v"(b.l[1]) : "v"(voW), "s"(srdW), "s"(so));
+    }
+  };
   auto step = [&](int s, int slot, int u, BFrag& bc, BFrag& bn) {
 #ifdef BSP_ABL_STAMP
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
@@ -268,12 +289,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
     wait_b(bc);
 #endif
 #ifdef BSP_ABL_STAMP
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
-#endif
-    if (u == 0) barrier_raw();           // stage S visible to all; everybody has finished reading stage S - 1
-#ifdef BSP_ABL_STAMP
-    const unsigned long long c2 = __builtin_amdgcn_s_memtime();
-    st_vm += c1 - c0; st_wait += c2 - c1;
+    st_vm += __builtin_amdgcn_s_memtime() - c0;
 #endif
     if (__builtin_expect((((s & 64) ? chg1 : chg0) >> (s & 63)) & 1ull, 0)) {
       const int de = etab[s] - etab[s - 1];
@@ -282,54 +298,59 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
     }
-#ifndef BSP_ABL_NOBLOAD
-    loadB(s + 2, bn);
-#endif
-    const char* st = lds + slot * KC_A;
-    f16x8 ah[4], al[4];
+    const char* sn = lds + (u ? (slot + 1) % KC_RING : slot) * KC_A;   // where sub-step s + 1 reads
+    const f16x8 bh0 = __builtin_bit_cast(f16x8, bc.h[0]), bh1 = __builtin_bit_cast(f16x8, bc.h[1]);
+    const f16x8 bl0 = __builtin_bit_cast(f16x8, bc.l[0]), bl1 = __builtin_bit_cast(f16x8, bc.l[1]);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-#ifdef BSP_ABL_NOLDSREAD
-      ah[mi] = __builtin_bit_cast(f16x8, bc.h[mi & 1]); al[mi] = __builtin_bit_cast(f16x8, bc.l[mi & 1]);
-#else
-      ah[mi] = ldsfrag(st + 4096 * mi + fo[u][0]);
-      al[mi] = ldsfrag(st + 4096 * mi + fo[u][1]);
-#endif
-    }
 #ifdef BSP_ABL_NOMFMA
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(ah[mi]), "v"(al[mi]), "v"(bc.h[0]), "v"(bc.l[0]), "v"(bc.h[1]), "v"(bc.l[1]));
+      asm volatile("" ::"v"(fa.h[mi]), "v"(fa.l[mi]), "v"(bc.h[0]), "v"(bc.l[0]), "v"(bc.h[1]), "v"(bc.l[1]));
 #else
-    // The three products of an accumulator tile (smallest first: hi*lo, lo*hi, hi*hi) are issued eight MFMAs apart, one
-    // term at a time over the eight tiles: a dependent MFMA straight behind its producer waits for the result to leave the
-    // pipe, and with the SIMD's other wave in its epilogue nothing fills that bubble.
-#pragma unroll
-    for (int term = 0; term < 3; ++term)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-        for (int nj = 0; nj < 2; ++nj)
-          acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term == 1 ? al[mi] : ah[mi],
-                                                               __builtin_bit_cast(f16x8, term == 0 ? bc.l[nj] : bc.h[nj]), acc[mi][nj], 0, 0, 0);
+      acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.h[mi], bl0, acc[mi][0], 0, 0, 0);
+      acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.h[mi], bl1, acc[mi][1], 0, 0, 0);
+#endif
+#ifndef BSP_ABL_NOBLOAD
+      if (mi < 2) loadB2(s + 2, bn, mi);
+#endif
 #ifndef BSP_ABL_NODMA
-        if (term == 1 && mi == 1) issueA((s >> 1) + 2, (slot + 2) % KC_RING, 2 * u);   // two of the four pieces of stage S + 2,
-        if (term == 2 && mi == 0) issueA((s >> 1) + 2, (slot + 2) % KC_RING, 2 * u + 1);   // under the MFMAs
+      if (mi >= 2) issueA((s >> 1) + 2, (slot + 2) % KC_RING, 2 * u + (mi - 2));   // two of the four pieces of stage S + 2
+#endif
+#ifndef BSP_ABL_NOMFMA
+      acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.l[mi], bh0, acc[mi][0], 0, 0, 0);
+      acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.l[mi], bh1, acc[mi][1], 0, 0, 0);
+#endif
+      if (mi == 0 && u == 1) {
+#ifdef BSP_ABL_STAMP
+        const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+#endif
+        __builtin_amdgcn_sched_barrier(0); barrier_raw(); __builtin_amdgcn_sched_barrier(0);
+#ifdef BSP_ABL_STAMP
+        st_wait += __builtin_amdgcn_s_memtime() - c2;
 #endif
       }
+#ifndef BSP_ABL_NOLDSREAD
+      const f16x8 nl = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
+#else
+      const f16x8 nl = __builtin_bit_cast(f16x8, bn.l[mi & 1]);
 #endif
-#if !defined(BSP_ABL_NOBLOAD) && !defined(BSP_ABL_NOLDSREAD) && !defined(BSP_ABL_NOMFMA) && !defined(BSP_ABL_NODMA)
-    // pin the order in the emitted code: the weight loads of step s + 1 go out FIRST (left alone, the scheduler sinks them
-    // to the end of the step to save registers and the next step then waits for L2 with nothing to do), then the eight
-    // fragment reads, then the MFMAs with the two DMA pieces in between
-    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#ifndef BSP_ABL_NOMFMA
+      acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.h[mi], bh0, acc[mi][0], 0, 0, 0);
+      acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa.h[mi], bh1, acc[mi][1], 0, 0, 0);
 #endif
+      fa.l[mi] = nl;
+#ifndef BSP_ABL_NOLDSREAD
+      fa.h[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);
+#else
+      fa.h[mi] = __builtin_bit_cast(f16x8, bn.h[mi & 1]);
+#endif
+      __builtin_amdgcn_sched_barrier(0);   // keep the blocks apart: left alone, the scheduler gathers the reads at the end
+    }
   };
+  // fragments of sub-step 0: stage 0 (and W(0)) are home when all but the eight youngest requests (W(1), stage 1) are
+  wait_vm<8>();
+  barrier_raw();
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) { fa.h[mi] = ldsfrag(lds + 4096 * mi + fo[0][0]); fa.l[mi] = ldsfrag(lds + 4096 * mi + fo[0][1]); }
   // The k-loop runs at raised priority: while the SIMD's other wave (the co-resident workgroup) is in its VALU-heavy
   // epilogue, MFMA issue goes first and the epilogue stream fills the 24 of every 32 cycles the matrix pipe leaves free.
 #ifndef BSP_KC_PRIO_LOOP
