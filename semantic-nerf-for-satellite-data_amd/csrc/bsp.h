@@ -98,7 +98,7 @@ struct KcArgs {
   // backward epilogue: multiply by the activation derivative rebuilt from the stored activation h (BSP, same shape as C)
   int aux_mode = AUX_NONE;           // AUX_SINREC: w0 sign sqrt(1 - h^2); AUX_RELU_MASK: h > 0
   const char* H = nullptr; const int* EH = nullptr; int ldh = 0; int h_col0 = 0; const unsigned* Hsign = nullptr;
-  float* colsum = nullptr; int ldcs = 0;   // per-32-row partial column sums of the stored values (bias gradients)
+  float* colsum = nullptr; int ldcs = 0;   // partial column sums of the stored values, one row per 128-row tile (bias gradients)
   int tiles_i = 0, tiles_j = 0;
 };
 // sign word of (32-row block, 64-column group, lane) of a tensor with `ld` columns: bit 8 ps + c <-> row (lane >> 3) + 8 ps,

@@ -189,9 +189,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
     voA2[q] = in ? (unsigned)row * (unsigned)p.lda2 * 4u + 16u * c : OOB;
   }
   char* const dst0 = lds + wave * 1024;
+  // The descriptor, the lanes' offsets and the stage bias of the segment being requested are loop-carried and replaced
+  // ONCE, at the stage where the second segment starts (selecting them per request cost ~16 scalar instructions per
+  // piece, more than an MFMA gap hides); a stage beyond K is rejected through the scalar offset.
+  srd_t srdCur = srdA;
+  unsigned voCur[4] = {voA[0], voA[1], voA[2], voA[3]};
+  int sbias = 0;
+  const int seg_switch = p.Ka < p.K ? nst1 : 0x7fffffff;
+  auto enter_stage = [&](int S) {     // before the first piece of stage S
+    if (__builtin_expect(S == seg_switch, 0)) {
+      srdCur = srdA2; sbias = nst1;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) voCur[q] = voA2[q];
+    }
+  };
   auto issueA = [&](int S, int slot, int q) {
-    const bool live = S < nst, seg2 = p.Ka < p.K && S >= nst1;
-    dma16(seg2 ? srdA2 : srdA, dst0 + slot * KC_A + 4096 * q, seg2 ? voA2[q] : voA[q], live ? (unsigned)(seg2 ? S - nst1 : S) * 128u : OOB);
+    dma16(srdCur, dst0 + slot * KC_A + 4096 * q, voCur[q], S < nst ? (unsigned)(S - sbias) * 128u : OOB);
   };
   // ---- W: fragment-ordered pack; unit (ks, rb32) = 2 KiB = [plane][lane][16 B]; this wave reads units rb32 = u0, u0 + 1
   const srd_words srdW = make_srd_words(p.W, p.w_bytes);
@@ -232,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   loadB(0, bq0);
   issueA(0, 0, 0); issueA(0, 0, 1); issueA(0, 0, 2); issueA(0, 0, 3);
   loadB(1, bq1);
+  enter_stage(1);
   issueA(1, 1, 0); issueA(1, 1, 1); issueA(1, 1, 2); issueA(1, 1, 3);
   if (wave == 0) { etab[sA] = eA; etab[sB] = eB; }
   const unsigned long long chg0 = __builtin_amdgcn_ballot_w64(eA != eAp), chg1 = __builtin_amdgcn_ballot_w64(eB != eBp);
@@ -313,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
       if (mi < 2) loadB2(s + 2, bn, mi);
 #endif
 #ifndef BSP_ABL_NODMA
+      if (mi == 2 && u == 0) enter_stage((s >> 1) + 2);
       if (mi >= 2) issueA((s >> 1) + 2, (slot + 2) % KC_RING, 2 * u + (mi - 2));   // two of the four pieces of stage S + 2
 #endif
 #ifndef BSP_ABL_NOMFMA
@@ -442,6 +457,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
     }
   };
   load_h(0, hh2[0], hl2[0], sword2[0]);
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // column sums over the tile's 128 rows (bias gradient partial)
+  // derivative epilogues: the accumulator's scale and |w0| in one factor; the sign bits are xor-ed with w0's own sign
+  const unsigned w0mag = __float_as_uint(fabsf(p.w0) * (AUX == AUX_SINREC ? inv_in : 1.f));
+  const float pre_scale = AUX == AUX_SINREC ? 1.f : inv_in;
 #pragma unroll
   for (int b = 0; b < 4; ++b) {          // 32-row blocks of the wave tile
     const int rbase = i0 + 32 * b;
@@ -454,8 +473,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) strip[((r & 3) + 8 * (r >> 2) + 4 * lh) * 68 + 32 * n + lc] = acc[b][n][r];
     unsigned sbits = 0u;
-    const unsigned swordx = sword ^ (p.w0 < 0.f ? 0xFFFFFFFFu : 0u), w0mag = __float_as_uint(fabsf(p.w0));
-    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const unsigned swordx = sword ^ (p.w0 < 0.f ? 0xFFFFFFFFu : 0u);
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const bool ok = col_ok && (rbase + rrow + 8 * ps) < p.I;
@@ -464,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
       const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       float v[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) v[c] = fmaf(x[c], inv_in, bj[c]);      // exact power of two, then + bias (SIREN: both times w0)
+      for (int c = 0; c < 8; ++c) v[c] = AUX == AUX_SINREC ? x[c] : fmaf(x[c], pre_scale, bj[c]);   // exact power of two, then + bias (SIREN: both times w0)
       if (ACT == ACT_SIN) {
         sbits |= sin8_signbits(v) << (8 * ps);
       } else if (ACT == ACT_RELU) {
@@ -481,8 +499,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
           for (int c = 0; c < 8; ++c) {
             float om;
             asm("v_fma_f32 %0, -%1, %1, 1.0 clamp" : "=v"(om) : "v"(h[c]));
-            const unsigned sh = swordx << (31 - (8 * ps + c));
-            const float w0s = __uint_as_float((sh & 0x80000000u) | w0mag);
+            unsigned w0s_bits;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(w0s_bits) : "s"(0x7fffffffu), "v"(w0mag), "v"(swordx << (31 - (8 * ps + c))));
+            const float w0s = __uint_as_float(w0s_bits);
             v[c] *= w0s * __builtin_amdgcn_sqrtf(om);
           }
         } else {
@@ -502,16 +521,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
     }
     if (ACT == ACT_SIN && p.Csign != nullptr && col_ok && rbase < p.I)
       p.Csign[((size_t)(rbase >> 5) * ((p.ldc + 63) >> 6) + ((p.c_col0 + j0 + wj0) >> 6)) * 64 + lane] = sbits;
-    if (COLSUM && p.colsum != nullptr) {
+  }
+  if (COLSUM && p.colsum != nullptr) {   // one partial row per 128-row tile: the lanes' sums over their 16 rows, then over the 8 row groups
 #pragma unroll
-      for (int o = 8; o < 64; o <<= 1)
+    for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
-        for (int c = 0; c < 8; ++c) cs[c] += __shfl_xor(cs[c], o, 64);
-      if (lane < 8 && col_ok && rbase < p.I) {
-        float* d = p.colsum + (size_t)(rbase >> 5) * p.ldcs + col;
-        *reinterpret_cast<float4*>(d) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-        *reinterpret_cast<float4*>(d + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
-      }
+      for (int c = 0; c < 8; ++c) cs[c] += __shfl_xor(cs[c], o, 64);
+    if (lane < 8 && col_ok) {
+      float* d = p.colsum + (size_t)ti * p.ldcs + col;
+      *reinterpret_cast<float4*>(d) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+      *reinterpret_cast<float4*>(d + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
     }
   }
 #ifdef BSP_ABL_STAMP

@@ -149,7 +149,7 @@ int dw_reduce(const Plan& p, const Ws& ws, const DwMat& m, size_t count, float* 
   return reduce_partials(ws.f(p.o_slab), m.sp.ns, m.stride, (int)count, ws.f(p.o_slab2), gout, st);
 }
 int bias_from_colsum(const Plan& p, const Ws& ws, int width, float* gout, hipStream_t st) {
-  return reduce_partials(ws.f(p.o_colsum), p.nrb, (size_t)p.maxw, width, ws.f(p.o_colsum2), gout, st);
+  return reduce_partials(ws.f(p.o_colsum), (p.P + 127) / 128, (size_t)p.maxw, width, ws.f(p.o_colsum2), gout, st);   // one partial row per 128-row tile
 }
 // bias gradient of a 32-wide pre-activation gradient; the same pass writes its planes + exponents (the dX / dW operands)
 int narrow_grad(const Plan& p, const Ws& ws, const float* dnar, char* planes, int* E, float* gout, hipStream_t st) {
