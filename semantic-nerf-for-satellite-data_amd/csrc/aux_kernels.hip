@@ -209,15 +209,43 @@ int launch_reduce_rows(const float* in, int n_in, size_t in_stride, int width, f
   return 0;
 }
 
-// two-level deterministic reduction of [n_in][stride] partials into out[width] (+=)
+// out[j] += sum_q in[q][j] over MANY partial rows in one launch: a workgroup owns 16 columns, its 16 row groups each sum
+// every 16th row (four accumulators, fixed order), then the 16 partial sums are added in group order.  Deterministic.
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const float* __restrict__ in, int n_in, size_t in_stride, int width,
+                                                          float* __restrict__ out) {
+  __shared__ float part[16][17];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (j < width) {
+    int q = rg;
+    for (; q + 48 < n_in; q += 64) {
+      s0 += in[(size_t)q * in_stride + j];
+      s1 += in[(size_t)(q + 16) * in_stride + j];
+      s2 += in[(size_t)(q + 32) * in_stride + j];
+      s3 += in[(size_t)(q + 48) * in_stride + j];
+    }
+    for (; q < n_in; q += 16) s0 += in[(size_t)q * in_stride + j];
+  }
+  part[rg][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && j < width) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += part[g][c];
+    out[j] += s;
+  }
+}
+
+// deterministic reduction of [n_in][stride] partials into out[width] (+=), one launch
 int reduce_partials(const float* in, int n_in, size_t in_stride, int width, float* tmp, float* out,
                     hipStream_t st) {
+  (void)tmp;
+  if (n_in <= 0 || width <= 0) return 0;
   if (n_in <= 64) return launch_reduce_rows(in, n_in, in_stride, width, out, 0, n_in, 1, st);
-  const int group = (n_in + 63) / 64;
-  const int ng = (n_in + group - 1) / group;
-  int rc = launch_reduce_rows(in, n_in, in_stride, width, tmp, (size_t)width, group, 0, st);
-  if (rc) return rc;
-  return launch_reduce_rows(tmp, ng, (size_t)width, width, out, 0, ng, 1, st);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((width + 15) / 16), dim3(256), 0, st, in, n_in, in_stride, width, out);
+  SNERF_LAUNCH_CHECK();
+  return 0;
 }
 
 // column sums of a [rows][32] buffer -> partial[blocks][32] (256 rows per block, float4 loads: 8 lanes per row)

@@ -11,6 +11,7 @@ from dataclasses import dataclass, field
 import torch
 
 import os
+import weakref
 
 from . import _lib
 
@@ -128,6 +129,42 @@ def _ptr(t):
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---- gradient sinks -------------------------------------------------------------------------------------------------
+# A parameter may have a registered SINK: a preallocated gradient tensor (FlatAdam's view into its flat bucket, which is
+# also p.grad).  A pass whose parameters all have one accumulates its packed gradients straight into the sinks
+# (snerf_unpack_grads, accumulate = 1) and returns no parameter gradients to autograd -- the 2 x 23 AccumulateGrad add
+# kernels per step (main + solar-correction pass, each parameter) disappear.  The two passes run their backward on
+# different HIP streams, so the unpack launches are chained by events (each waits for the previous one; with two
+# contributions the sum is the same in either order).  Parameters without sinks (tests, foreign optimisers) get their
+# gradients from autograd as before.  SNERF_GRAD_SINKS=0 switches the mechanism off (A/B).
+_GRAD_SINKS: dict = {}      # id(parameter) -> (weakref, sink tensor)
+_SINK_EVENT: dict = {}      # device index -> event of the last accumulating unpack
+_SINK_TOUCHED: set = set()  # ids of parameters whose sink a pass has accumulated into (cleared by the optimiser's zero_grad)
+_SINKS_ON = os.environ.get("SNERF_GRAD_SINKS", "1") != "0"
+
+
+def register_grad_sinks(params, sinks):
+    for p, g in zip(params, sinks):
+        _GRAD_SINKS[id(p)] = (weakref.ref(p), g)
+
+
+def unregister_grad_sinks(params):
+    for p in params:
+        _GRAD_SINKS.pop(id(p), None)
+
+
+def _sinks_for(params):
+    if not _SINKS_ON or not _GRAD_SINKS:
+        return None
+    out = []
+    for p in params:
+        e = _GRAD_SINKS.get(id(p))
+        if e is None or e[0]() is not p or p.grad is None or p.grad.data_ptr() != e[1].data_ptr():
+            return None      # not (or no longer) wired to its sink: autograd accumulates
+        out.append(e[1])
+    return out
 
 
 def _check_dev(t: torch.Tensor, name: str):
@@ -304,8 +341,21 @@ class _RenderPass(torch.autograd.Function):
             _lib.check(L.snerf_backward(C.byref(d), _ptr(ctx.packed), C.byref(si), C.byref(go), _ptr(pg), _ptr(d_t),
                                         _ptr(d_ts), _ptr(ctx.ws), ctx.nbytes, _stream()), "snerf_backward")
         like = dict(zip(ctx.names, ctx.param_like))
-        grads = unpack_grads(spec, pg, like)
         ctx.ws = None
+        sinks = _sinks_for(ctx.param_like)
+        if sinks is not None:
+            with torch.cuda.device(dev):
+                st = torch.cuda.current_stream()
+                prev = _SINK_EVENT.get(dev.index)
+                if prev is not None:
+                    st.wait_event(prev)
+                unpack_grads(spec, pg, like, accumulate_into=dict(zip(ctx.names, sinks)))
+                _SINK_TOUCHED.update(id(p) for p in ctx.param_like)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                _SINK_EVENT[dev.index] = ev
+            return (None, None, None, None, None, None, d_t, d_ts) + (None,) * len(ctx.names)
+        grads = unpack_grads(spec, pg, like)
         # EVERY parameter gets a gradient tensor, zero where no result gradient reaches it: the reference's model returns
         # one concatenated (P, 9 + C) tensor that inference() slices (semantic/models/rs_semantic.py:71-96), so autograd
         # hands e.g. the beta head exact ZEROS (not None) while epoch < first_beta_epoch, and torch.optim.Adam counts

@@ -23,7 +23,7 @@ class FlatAdam:
     """torch.optim.Adam surface (param_groups, step, zero_grad, state_dict) over flat buffers."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0):
+                 weight_decay: float = 0.0, grad_sinks: bool = True):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatAdam: no trainable parameters")
@@ -57,6 +57,16 @@ class FlatAdam:
         # bookkeeping so that optimizer_states written by either side load into the other.  (In the pipelines every
         # parameter has a gradient every step -- the reference's concatenated model output makes autograd hand unused
         # heads exact zeros, not None -- so all counts are equal there and the update is one launch.)
+        # the .grad views double as gradient sinks of the fused passes (ops.register_grad_sinks): while a parameter's
+        # .grad IS its view, the passes accumulate into it directly and autograd launches no add kernel for it
+        from . import ops
+        self.sinks = bool(grad_sinks) and ops._SINKS_ON
+        if self.sinks:
+            ops.register_grad_sinks(self.params, self._gviews)
+            # a gradient that plain autograd accumulates into a view in place (a loss outside the fused passes) marks the
+            # parameter as written too, so that "still the zeroed view" can be told from "has a gradient"
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(lambda q: ops._SINK_TOUCHED.add(id(q)))
         self.steps = [0] * len(self.params)
         self._active = None
         self.param_groups = [{"lr": float(lr), "betas": tuple(betas), "eps": float(eps), "weight_decay": 0.0,
@@ -64,12 +74,16 @@ class FlatAdam:
 
     # ---- torch.optim surface ------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True):
-        """set_to_none (default, as torch): drop the .grad references -- autograd then hands over each pass's gradient
-        tensors without an add kernel per parameter, and step() gathers them into the flat buffer with one
-        multi-tensor copy.  set_to_none=False: one memset, .grad stays a view of the flat buffer and autograd
-        accumulates into it in place."""
+        """With gradient sinks (the default): one memset, every .grad stays the view of the flat buffer that the fused
+        passes accumulate into.  Without (SNERF_GRAD_SINKS=0): set_to_none (default, as torch) drops the .grad
+        references -- autograd then hands over each pass's gradient tensors and step() gathers them into the flat buffer
+        with one multi-tensor copy; set_to_none=False: one memset, autograd accumulates into the views in place."""
         self._active = None
-        if set_to_none:
+        self._none_mode = bool(set_to_none)   # torch: zero_grad(set_to_none=False) leaves zero TENSORS, which Adam steps
+        if self.sinks:
+            from . import ops
+            ops._SINK_TOUCHED.difference_update(id(p) for p in self.params)
+        if set_to_none and not self.sinks:
             for p in self.params:
                 p.grad = None
             return
@@ -86,10 +100,17 @@ class FlatAdam:
         if self._active is not None:      # already gathered for this step (TrainLoop calls this before the all-reduce)
             return
         src, dst, active = [], [], []
+        touched = None
+        if self.sinks and getattr(self, "_none_mode", True):
+            from . import ops
+            touched = ops._SINK_TOUCHED
         for p, g in zip(self.params, self._gviews):
-            active.append(p.grad is not None)
-            if p.grad is None:
-                g.zero_()
+            # with sinks, a .grad that is still the (zeroed) view and that no pass has written counts as "no gradient"
+            has = p.grad is not None and not (touched is not None and p.grad is g and id(p) not in touched)
+            active.append(has)
+            if not has:
+                if p.grad is None:
+                    g.zero_()     # (an untouched view is still zero from zero_grad's memset)
             elif p.grad.data_ptr() != g.data_ptr():
                 src.append(p.grad.detach())
                 dst.append(g)
