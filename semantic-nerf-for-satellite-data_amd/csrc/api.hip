@@ -125,23 +125,8 @@ static void plan_bsp(Plan& p) {
     p.o_pdsig = planes(NARROW); p.e_dsig = etab(NARROW);
     p.o_pdfin = planes(NARROW); p.e_dfin = etab(NARROW);
     p.o_pdsun = planes(NARROW); p.e_dsun = etab(NARROW);
-    p.o_colsum = wtake((size_t)p.nrb * p.maxw * 4);
-    p.o_colsum2 = wtake((size_t)64 * (p.maxw > p.sky_floats ? p.maxw : p.sky_floats) * 4);
-    auto need = [&](int rows, int ld, int cols, bool narrow) {
-      const DwSplit d = dw_choose_bsp(p.P, rows, cols, narrow);
-      return round_up_sz((size_t)rows * ld, 64) * d.ns;
-    };
-    size_t cap = need(p.h1w, p.FA, p.FA, false);
-    for (int i = 0; i < p.L; ++i) { const size_t c = need(p.W, p.k_tr[i], p.W, false); if (c > cap) cap = c; }
-    size_t c2 = need(p.W + NARROW, p.W, p.W, false); if (c2 > cap) cap = c2;
-    c2 = need(NARROW, p.KF, p.KF, true); if (c2 > cap) cap = c2;
-    c2 = need(NARROW, p.H, p.H, true); if (c2 > cap) cap = c2;
-    c2 = need(p.H, p.H, p.H, false); if (c2 > cap) cap = c2;
-    p.slab_floats = cap;
-    p.o_slab = wtake(p.slab_floats * 4);
-    { size_t big = (size_t)p.N1 * p.FA; for (int i = 0; i < p.L; ++i) if ((size_t)p.W * p.k_tr[i] > big) big = (size_t)p.W * p.k_tr[i];
-      if ((size_t)(p.W + NARROW) * p.W > big) big = (size_t)(p.W + NARROW) * p.W; if ((size_t)NARROW * p.KF > big) big = (size_t)NARROW * p.KF;
-      p.o_slab2 = wtake(64 * round_up_sz(big, 64) * 4); }
+    p.rq_floats = bsp_rq_floats(p);
+    p.o_rq = wtake(p.rq_floats * 4);
     p.o_skyslab = wtake((size_t)p.comp_blocks * 4 * p.sky_floats * 4);
   }
   p.ws_bytes = wo;

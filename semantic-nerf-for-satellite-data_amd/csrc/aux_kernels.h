@@ -30,6 +30,13 @@ int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes
 int launch_reduce_rows(const float* in, int n_in, size_t in_stride, int width, float* out, size_t out_stride,
                        int group, int accumulate, hipStream_t st);
 int reduce_partials(const float* in, int n_in, size_t in_stride, int width, float* tmp, float* out, hipStream_t st);
+// batched reductions (aux_kernels.hip): out[e] += sum_q in[q * stride + e], all jobs of a pass in two launches
+struct RedJob { const float* in; float* out; unsigned long long stride; long long width; int n_in; int blk0; int vec; int pad; };
+constexpr int RED_MAX = 56;
+struct RedTable { RedJob j[RED_MAX]; int n = 0; int blocks = 0; };
+int red_add_elem(RedTable& tb, const float* in, int n_in, size_t stride, size_t width, float* out);   // few slabs, many elements
+int red_add_col(RedTable& tb, const float* in, int n_in, size_t stride, int width, float* out);       // many partial rows, <= ~1024 columns
+int launch_reductions(const RedTable& elem, const RedTable& col, hipStream_t st);
 int colsum32_blocks(int rows);   // partial rows launch_colsum32 writes
 int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st);
 int launch_ray_sum(const float* dfa, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st);

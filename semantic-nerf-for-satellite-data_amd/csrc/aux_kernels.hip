@@ -248,6 +248,90 @@ int reduce_partials(const float* in, int n_in, size_t in_stride, int width, floa
   return 0;
 }
 
+// ---- batched reductions: every slab / column-sum reduction of a backward pass in TWO launches ------------------------
+// out[e] += sum_{q < n_in} in[q * stride + e]; job tables travel as kernel arguments.  Fixed order -> deterministic.
+// "elem" jobs (dW split slabs: few rows, many elements): a thread owns four consecutive elements (or one, `vec` = 0) and
+// walks the slabs; "col" jobs (column-sum partials: thousands of rows, <= 1024 columns): reduce_cols_kernel's scheme.
+__global__ __launch_bounds__(256) void reduce_elem_jobs_kernel(const RedTable tb) {
+  int k = 0;
+  while (k + 1 < tb.n && (int)blockIdx.x >= tb.j[k + 1].blk0) ++k;
+  const RedJob jb = tb.j[k];
+  const size_t e = ((size_t)(blockIdx.x - jb.blk0) * 256 + threadIdx.x) * (jb.vec ? 4 : 1);
+  if (e >= (size_t)jb.width) return;
+  if (jb.vec) {
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    int q = 0;
+    for (; q + 1 < jb.n_in; q += 2) {
+      const float4 a = *reinterpret_cast<const float4*>(jb.in + (size_t)q * jb.stride + e);
+      const float4 b = *reinterpret_cast<const float4*>(jb.in + (size_t)(q + 1) * jb.stride + e);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    }
+    if (q < jb.n_in) { const float4 a = *reinterpret_cast<const float4*>(jb.in + (size_t)q * jb.stride + e); s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
+    float4* o = reinterpret_cast<float4*>(jb.out + e);
+    float4 v = *o;
+    v.x += s0.x + s1.x; v.y += s0.y + s1.y; v.z += s0.z + s1.z; v.w += s0.w + s1.w;
+    *o = v;
+  } else {
+    float s0 = 0.f, s1 = 0.f;
+    int q = 0;
+    for (; q + 1 < jb.n_in; q += 2) { s0 += jb.in[(size_t)q * jb.stride + e]; s1 += jb.in[(size_t)(q + 1) * jb.stride + e]; }
+    if (q < jb.n_in) s0 += jb.in[(size_t)q * jb.stride + e];
+    jb.out[e] += s0 + s1;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_col_jobs_kernel(const RedTable tb) {
+  __shared__ float part[16][17];
+  int k = 0;
+  while (k + 1 < tb.n && (int)blockIdx.x >= tb.j[k + 1].blk0) ++k;
+  const RedJob jb = tb.j[k];
+  const int c = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int j = ((int)blockIdx.x - jb.blk0) * 16 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (j < jb.width) {
+    int q = rg;
+    for (; q + 48 < jb.n_in; q += 64) {
+      s0 += jb.in[(size_t)q * jb.stride + j];
+      s1 += jb.in[(size_t)(q + 16) * jb.stride + j];
+      s2 += jb.in[(size_t)(q + 32) * jb.stride + j];
+      s3 += jb.in[(size_t)(q + 48) * jb.stride + j];
+    }
+    for (; q < jb.n_in; q += 16) s0 += jb.in[(size_t)q * jb.stride + j];
+  }
+  part[rg][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && j < jb.width) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += part[g][c];
+    jb.out[j] += s;
+  }
+}
+
+int red_add_elem(RedTable& tb, const float* in, int n_in, size_t stride, size_t width, float* out) {
+  if (n_in <= 0 || width == 0) return 0;
+  if (tb.n >= RED_MAX) { set_error("reduction queue full"); return SNERF_ERR_WORKSPACE; }
+  RedJob& j = tb.j[tb.n++];
+  j.in = in; j.out = out; j.stride = stride; j.n_in = n_in; j.width = (long long)width; j.blk0 = tb.blocks;
+  j.vec = ((width & 3) == 0 && (stride & 3) == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+  tb.blocks += (int)((width / (j.vec ? 4 : 1) + 255) / 256);
+  return 0;
+}
+int red_add_col(RedTable& tb, const float* in, int n_in, size_t stride, int width, float* out) {
+  if (n_in <= 0 || width <= 0) return 0;
+  if (tb.n >= RED_MAX) { set_error("reduction queue full"); return SNERF_ERR_WORKSPACE; }
+  RedJob& j = tb.j[tb.n++];
+  j.in = in; j.out = out; j.stride = stride; j.n_in = n_in; j.width = width; j.blk0 = tb.blocks; j.vec = 0;
+  tb.blocks += (width + 15) / 16;
+  return 0;
+}
+int launch_reductions(const RedTable& elem, const RedTable& col, hipStream_t st) {
+  if (elem.n > 0) { hipLaunchKernelGGL(reduce_elem_jobs_kernel, dim3(elem.blocks), dim3(256), 0, st, elem); SNERF_LAUNCH_CHECK(); }
+  if (col.n > 0) { hipLaunchKernelGGL(reduce_col_jobs_kernel, dim3(col.blocks), dim3(256), 0, st, col); SNERF_LAUNCH_CHECK(); }
+  return 0;
+}
+
 // column sums of a [rows][32] buffer -> partial[blocks][32] (256 rows per block, float4 loads: 8 lanes per row)
 constexpr int CS32_ROWS = 256;
 __global__ __launch_bounds__(256) void colsum32_kernel(const float* __restrict__ in, int rows, float* __restrict__ partial) {

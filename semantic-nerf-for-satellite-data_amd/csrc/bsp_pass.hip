@@ -126,38 +126,69 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
 
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
-struct DwMat { DwSplit sp; size_t stride; int ldw; };
-DwMat dw_begin(const Plan& p, int rows, int ldw, int cols, bool narrow_rows) {
+// Deferred reductions: every dW launch writes its split slabs, every dX launch its column-sum partials, into a region of
+// its OWN inside the reduction arena (p.o_rq); the reductions into the packed gradient buffer are queued and run as two
+// launches at the end of the pass (aux_kernels.hip: launch_reductions) instead of ~60 small ones in between the GEMMs.
+struct RQ {
+  float* base; size_t cap, used = 0; bool over = false;
+  RedTable elem, col;
+  float* take(size_t floats) {
+    const size_t n = round_up_sz(floats, 64);
+    if (used + n > cap) { over = true; return base; }
+    float* r = base + used; used += n; return r;
+  }
+};
+struct DwMat { DwSplit sp; size_t stride; int ldw; float* slab; };
+DwMat dw_begin(const Plan& p, RQ& rq, int rows, int ldw, int cols, bool narrow_rows) {
   DwMat m;
   m.sp = dw_choose_bsp(p.P, rows, cols, narrow_rows);
   m.stride = round_up_sz((size_t)rows * ldw, 64);
   m.ldw = ldw;
+  m.slab = rq.take(m.stride * m.sp.ns);
   return m;
 }
 // slab[split][i][slab_off + j] = sum_p dZ[p][dz_col0 + i] X[p][x_col0 + j]
-int dw_gemm(const Plan& p, const Ws& ws, const DwMat& m, const char* dz, const int* edz, int lddz, int dz_col0, int I, bool narrow_i,
+int dw_gemm(const Plan& p, const DwMat& m, const char* dz, const int* edz, int lddz, int dz_col0, int I, bool narrow_i,
             const char* X, const int* ex, int ldx, int x_col0, int J, size_t slab_off, hipStream_t st) {
   bsp::DwArgs g;
   g.A = dz; g.EA = edz; g.lda = lddz; g.a_col0 = dz_col0;
   g.B = X; g.EB = ex; g.ldb = ldx; g.b_col0 = x_col0;
   g.I = I; g.J = J; g.P = p.P;
-  g.C = ws.f(p.o_slab) + slab_off; g.ldc = m.ldw;
+  g.C = m.slab + slab_off; g.ldc = m.ldw;
   g.k_split = m.sp.k_split; g.n_split = m.sp.ns; g.slab_stride = m.stride;
   return bsp::launch_dw(g, narrow_i, st);
 }
-int dw_reduce(const Plan& p, const Ws& ws, const DwMat& m, size_t count, float* gout, hipStream_t st) {
-  return reduce_partials(ws.f(p.o_slab), m.sp.ns, m.stride, (int)count, ws.f(p.o_slab2), gout, st);
-}
-int bias_from_colsum(const Plan& p, const Ws& ws, int width, float* gout, hipStream_t st) {
-  return reduce_partials(ws.f(p.o_colsum), (p.P + 127) / 128, (size_t)p.maxw, width, ws.f(p.o_colsum2), gout, st);   // one partial row per 128-row tile
+int dw_reduce(RQ& rq, const DwMat& m, size_t count, float* gout) { return red_add_elem(rq.elem, m.slab, m.sp.ns, m.stride, count, gout); }
+// column-sum partials of a dX launch: one row per 128-row tile, `width` columns
+inline int cs_ld(int width) { return (width + 3) & ~3; }
+float* cs_take(const Plan& p, RQ& rq, int width) { return rq.take((size_t)((p.P + 127) / 128) * cs_ld(width)); }
+int bias_from_colsum(const Plan& p, RQ& rq, const float* cs, int width, float* gout) {
+  return red_add_col(rq.col, cs, (p.P + 127) / 128, (size_t)cs_ld(width), width, gout);
 }
 // bias gradient of a 32-wide pre-activation gradient; the same pass writes its planes + exponents (the dX / dW operands)
-int narrow_grad(const Plan& p, const Ws& ws, const float* dnar, char* planes, int* E, float* gout, hipStream_t st) {
+int narrow_grad(const Plan& p, RQ& rq, const float* dnar, char* planes, int* E, float* gout, hipStream_t st) {
   const int nb = (p.P + 255) / 256;
-  RC(bsp::launch_colsum32_bsp(dnar, p.P, ws.f(p.o_colsum), planes, E, st));
-  return reduce_partials(ws.f(p.o_colsum), nb, NARROW, NARROW, ws.f(p.o_colsum2), gout, st);
+  float* part = rq.take((size_t)nb * NARROW);
+  RC(bsp::launch_colsum32_bsp(dnar, p.P, part, planes, E, st));
+  return red_add_col(rq.col, part, nb, NARROW, NARROW, gout);
 }
 }  // namespace
+
+// floats of the reduction arena: the same sequence of takes as backward_bsp below
+size_t bsp_rq_floats(const Plan& p) {
+  size_t n = 0;
+  auto take = [&](size_t f) { n += round_up_sz(f, 64); };
+  auto slab = [&](int rows, int ldw, int cols, bool narrow) { take(round_up_sz((size_t)rows * ldw, 64) * dw_choose_bsp(p.P, rows, cols, narrow).ns); };
+  auto cs = [&](int width) { take((size_t)((p.P + 127) / 128) * ((width + 3) & ~3)); };
+  auto nar = [&]() { take((size_t)((p.P + 255) / 256) * NARROW); };
+  const int W = p.W, H = p.H;
+  if (!p.sc) { nar(); slab(NARROW, p.KF, p.KF, true); cs(p.KF); }
+  nar(); slab(NARROW, H, H, true); slab(H, H, H, false); slab(H, H, H, false); cs(H); cs(H); cs(H);
+  slab(p.h1w, p.FA, p.FA, false); cs(p.FA);
+  nar(); slab(W + NARROW, W, W, false); cs(W);
+  for (int i = p.L - 1; i >= 0; --i) { slab(W, p.k_tr[i], i == 0 ? p.Ep : W, false); if (i > 0) cs(W); }
+  return n;
+}
 
 int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutGrads* go, float* gp, float* d_t, float* d_t_s,
                  void* workspace, hipStream_t st) {
@@ -169,8 +200,10 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     g.H = ws.c(o_h); g.EH = ws.i(e_h); g.ldh = ld; g.h_col0 = col0;
     if (p.siren) { g.aux_mode = AUX_SINREC; g.Hsign = ws.u(o_c); g.w0 = w0; }
     else g.aux_mode = AUX_RELU_MASK;
-    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
   };
+  RQ rq{ws.f(p.o_rq), p.rq_floats};
+  auto colsum = [&](bsp::KcArgs& g, int width) { g.colsum = cs_take(p, rq, width); g.ldcs = cs_ld(width); return g.colsum; };
+  const float* cs_ = nullptr;
   float* dsig = ws.f(p.o_dsig); float* dfin = ws.f(p.o_dfin); float* dsun = ws.f(p.o_dsun);
   // 0. composite backward -> gradients of the 32-wide pre-activations (+ sky MLP grads)
   CompBwdArgs b;
@@ -185,81 +218,86 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
   b.d_sigo = dsig; b.d_fino = dfin; b.d_suno = dsun; b.sky_slab = p.sc ? nullptr : ws.f(p.o_skyslab);
   RC(launch_composite_bwd(b, st));
   if (!p.sc)
-    RC(reduce_partials(ws.f(p.o_skyslab), p.comp_blocks * 4, (size_t)p.sky_floats, p.sky_floats, ws.f(p.o_colsum2), gp + p.sky, st));
+    RC(red_add_col(rq.col, ws.f(p.o_skyslab), p.comp_blocks * 4, (size_t)p.sky_floats, p.sky_floats, gp + p.sky));
 
   char* dz1 = ws.c(p.o_dza); int* edz1 = ws.i(p.e_dza);   // d(pre-activation) of the fused first head layer, [P][h1w]
   const int sun_col = p.sc ? 0 : p.sun_col;
   if (!p.sc) {
     // 1. final head layers: bias gradient + planes of dfin, dW, then dz1[:, :KF] = (dfin . W_fin) * act'
-    RC(narrow_grad(p, ws, dfin, ws.c(p.o_pdfin), ws.i(p.e_dfin), gp + p.b_fin, st));
-    const DwMat mf = dw_begin(p, NARROW, p.KF, p.KF, true);
-    RC(dw_gemm(p, ws, mf, ws.c(p.o_pdfin), ws.i(p.e_dfin), NARROW, 0, NARROW, true, ws.c(p.o_h1), ws.i(p.e_h1), p.h1w, 0, p.KF, 0, st));
-    RC(dw_reduce(p, ws, mf, (size_t)NARROW * p.KF, gp + p.w_fin, st));
+    RC(narrow_grad(p, rq, dfin, ws.c(p.o_pdfin), ws.i(p.e_dfin), gp + p.b_fin, st));
+    const DwMat mf = dw_begin(p, rq, NARROW, p.KF, p.KF, true);
+    RC(dw_gemm(p, mf, ws.c(p.o_pdfin), ws.i(p.e_dfin), NARROW, 0, NARROW, true, ws.c(p.o_h1), ws.i(p.e_h1), p.h1w, 0, p.KF, 0, st));
+    RC(dw_reduce(rq, mf, (size_t)NARROW * p.KF, gp + p.w_fin));
     bsp::KcArgs g;
     g.A = ws.c(p.o_pdfin); g.EA = ws.i(p.e_dfin); g.lda = NARROW; g.Ka = NARROW; weights(g, p, pk, p.wj_tfin);
     g.I = P; g.J = p.KF; g.K = NARROW; g.C = dz1; g.EC = edz1; g.ldc = p.h1w;
     dact(g, p.o_c1, p.o_h1, p.e_h1, p.h1w);
+    cs_ = colsum(g, p.KF);
     RC(bsp::launch_kc(g, st));
-    RC(bias_from_colsum(p, ws, p.KF, gp + p.b_h1, st));
+    RC(bias_from_colsum(p, rq, cs_, p.KF, gp + p.b_h1));
   }
   {  // 2. sun visibility chain: output layer, layer 3, layer 2
-    RC(narrow_grad(p, ws, dsun, ws.c(p.o_pdsun), ws.i(p.e_dsun), gp + p.b_s4, st));
-    const DwMat m4 = dw_begin(p, NARROW, H, H, true);
-    const DwMat mh = dw_begin(p, H, H, H, false);
-    RC(dw_gemm(p, ws, m4, ws.c(p.o_pdsun), ws.i(p.e_dsun), NARROW, 0, NARROW, true, ws.c(p.o_s3), ws.i(p.e_s3), H, 0, H, 0, st));
-    RC(dw_reduce(p, ws, m4, (size_t)NARROW * H, gp + p.w_s4, st));
+    RC(narrow_grad(p, rq, dsun, ws.c(p.o_pdsun), ws.i(p.e_dsun), gp + p.b_s4, st));
+    const DwMat m4 = dw_begin(p, rq, NARROW, H, H, true);
+    const DwMat mh = dw_begin(p, rq, H, H, H, false), mh2 = dw_begin(p, rq, H, H, H, false);   // one slab region per matrix
+    RC(dw_gemm(p, m4, ws.c(p.o_pdsun), ws.i(p.e_dsun), NARROW, 0, NARROW, true, ws.c(p.o_s3), ws.i(p.e_s3), H, 0, H, 0, st));
+    RC(dw_reduce(rq, m4, (size_t)NARROW * H, gp + p.w_s4));
     bsp::KcArgs g;
     g.A = ws.c(p.o_pdsun); g.EA = ws.i(p.e_dsun); g.lda = NARROW; g.Ka = NARROW; weights(g, p, pk, p.wj_ts4);
     g.I = P; g.J = H; g.K = NARROW; g.C = ws.c(p.o_dsa); g.EC = ws.i(p.e_dsa); g.ldc = H;
     dact(g, p.o_cs3, p.o_s3, p.e_s3, H);
+    cs_ = colsum(g, H);
     RC(bsp::launch_kc(g, st));  // dz_s3
-    RC(bias_from_colsum(p, ws, H, gp + p.b_s3, st));
-    RC(dw_gemm(p, ws, mh, ws.c(p.o_dsa), ws.i(p.e_dsa), H, 0, H, false, ws.c(p.o_s2), ws.i(p.e_s2), H, 0, H, 0, st));
-    RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s3, st));
+    RC(bias_from_colsum(p, rq, cs_, H, gp + p.b_s3));
+    RC(dw_gemm(p, mh, ws.c(p.o_dsa), ws.i(p.e_dsa), H, 0, H, false, ws.c(p.o_s2), ws.i(p.e_s2), H, 0, H, 0, st));
+    RC(dw_reduce(rq, mh, (size_t)H * H, gp + p.w_s3));
     g.A = ws.c(p.o_dsa); g.EA = ws.i(p.e_dsa); g.lda = H; g.Ka = H; g.K = H; weights(g, p, pk, p.wj_ts3);
     g.C = ws.c(p.o_dsb); g.EC = ws.i(p.e_dsb);
     dact(g, p.o_cs2, p.o_s2, p.e_s2, H);
+    cs_ = colsum(g, H);
     RC(bsp::launch_kc(g, st));  // dz_s2
-    RC(bias_from_colsum(p, ws, H, gp + p.b_s2, st));
-    RC(dw_gemm(p, ws, mh, ws.c(p.o_dsb), ws.i(p.e_dsb), H, 0, H, false, ws.c(p.o_h1), ws.i(p.e_h1), p.h1w, sun_col, H, 0, st));
-    RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s2, st));
+    RC(bias_from_colsum(p, rq, cs_, H, gp + p.b_s2));
+    RC(dw_gemm(p, mh2, ws.c(p.o_dsb), ws.i(p.e_dsb), H, 0, H, false, ws.c(p.o_h1), ws.i(p.e_h1), p.h1w, sun_col, H, 0, st));
+    RC(dw_reduce(rq, mh2, (size_t)H * H, gp + p.w_s2));
     g.A = ws.c(p.o_dsb); g.EA = ws.i(p.e_dsb); weights(g, p, pk, p.wj_ts2);
     g.C = dz1; g.EC = edz1; g.ldc = p.h1w; g.c_col0 = sun_col;
     dact(g, p.o_c1, p.o_h1, p.e_h1, p.h1w, sun_col);
+    cs_ = colsum(g, H);
     RC(bsp::launch_kc(g, st));  // dz1[:, sun block]
-    RC(bias_from_colsum(p, ws, H, gp + p.b_h1 + (size_t)p.sun_col, st));
+    RC(bias_from_colsum(p, rq, cs_, H, gp + p.b_h1 + (size_t)p.sun_col));
   }
   char* dfa = ws.c(p.o_dzb); int* edfa = ws.i(p.e_dzb);   // [P][FA]
   {  // 3. fused first head layer: dW, then d[feats | extras]
     const int r0 = p.sc ? p.sun_col : 0;
-    const DwMat m1 = dw_begin(p, p.h1w, p.FA, p.FA, false);
-    RC(dw_gemm(p, ws, m1, dz1, edz1, p.h1w, 0, p.h1w, false, ws.c(p.o_fa), ws.i(p.e_fa), p.FA, 0, p.FA, 0, st));
-    RC(dw_reduce(p, ws, m1, (size_t)p.h1w * p.FA, gp + p.w_h1 + (size_t)r0 * p.FA, st));
+    const DwMat m1 = dw_begin(p, rq, p.h1w, p.FA, p.FA, false);
+    RC(dw_gemm(p, m1, dz1, edz1, p.h1w, 0, p.h1w, false, ws.c(p.o_fa), ws.i(p.e_fa), p.FA, 0, p.FA, 0, st));
+    RC(dw_reduce(rq, m1, (size_t)p.h1w * p.FA, gp + p.w_h1 + (size_t)r0 * p.FA));
     bsp::KcArgs g;
     g.A = dz1; g.EA = edz1; g.lda = p.h1w; g.Ka = p.h1w; weights(g, p, pk, p.wj_th1, 0, r0);
     g.I = P; g.J = p.FA; g.K = p.h1w; g.C = dfa; g.EC = edfa; g.ldc = p.FA;
-    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;   // columns [0, W) = bias gradient of feats_from_xyz
+    cs_ = colsum(g, p.FA);   // columns [0, W) = bias gradient of feats_from_xyz
     RC(bsp::launch_kc(g, st));
-    RC(bias_from_colsum(p, ws, W, gp + p.b_fs, st));
+    RC(red_add_col(rq.col, cs_, (P + 127) / 128, (size_t)cs_ld(p.FA), W, gp + p.b_fs));
     if (d_t) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_t, p.N, p.S, p.tau, d_t, st));
     if (d_t_s && p.x_ts >= 0) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_ts, p.N, p.S, p.tau, d_t_s, st));
   }
   char* dz = ws.c(p.o_dza); int* edz = ws.i(p.e_dza);   // dz1 is dead from here on
   {  // 4. feats + sigma: dW for the [W + 32][W] matrix, then dz of the last trunk layer
     const char* hl = ws.c(p.o_h[p.L - 1]); const int* ehl = ws.i(p.e_h[p.L - 1]);
-    RC(narrow_grad(p, ws, dsig, ws.c(p.o_pdsig), ws.i(p.e_dsig), gp + p.b_fs + W, st));
-    const DwMat ms = dw_begin(p, W + NARROW, W, W, false);
-    RC(dw_gemm(p, ws, ms, dfa, edfa, p.FA, 0, W, false, hl, ehl, W, 0, W, 0, st));
-    RC(dw_gemm(p, ws, ms, ws.c(p.o_pdsig), ws.i(p.e_dsig), NARROW, 0, NARROW, true, hl, ehl, W, 0, W, (size_t)W * W, st));
-    RC(dw_reduce(p, ws, ms, (size_t)(W + NARROW) * W, gp + p.w_fs, st));
+    RC(narrow_grad(p, rq, dsig, ws.c(p.o_pdsig), ws.i(p.e_dsig), gp + p.b_fs + W, st));
+    const DwMat ms = dw_begin(p, rq, W + NARROW, W, W, false);
+    RC(dw_gemm(p, ms, dfa, edfa, p.FA, 0, W, false, hl, ehl, W, 0, W, 0, st));
+    RC(dw_gemm(p, ms, ws.c(p.o_pdsig), ws.i(p.e_dsig), NARROW, 0, NARROW, true, hl, ehl, W, 0, W, (size_t)W * W, st));
+    RC(dw_reduce(rq, ms, (size_t)(W + NARROW) * W, gp + p.w_fs));
     bsp::KcArgs g;
     g.A = dfa; g.EA = edfa; g.lda = p.FA; g.Ka = W;
     g.A2 = ws.c(p.o_pdsig); g.EA2 = ws.i(p.e_dsig); g.lda2 = NARROW;
     weights(g, p, pk, p.wj_tfs); g.I = P; g.J = W; g.K = W + NARROW;
     g.C = dz; g.EC = edz; g.ldc = W;
     dact(g, p.o_c[p.L - 1], p.o_h[p.L - 1], p.e_h[p.L - 1], W, 0, (p.L == 1) ? 30.f : 1.f);
+    cs_ = colsum(g, W);
     RC(bsp::launch_kc(g, st));
-    RC(bias_from_colsum(p, ws, W, gp + p.b_tr[p.L - 1], st));
+    RC(bias_from_colsum(p, rq, cs_, W, gp + p.b_tr[p.L - 1]));
   }
   // 5. trunk, last layer to first
   char* dz_cur = dz; int* edz_cur = edz;
@@ -267,21 +305,23 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
   for (int i = p.L - 1; i >= 0; --i) {
     const bool skip = (p.skip_mask >> i) & 1u;
     const int hoff = (i > 0 && skip) ? p.Ep : 0;  // column of the h part inside W_i
-    const DwMat mt = dw_begin(p, W, p.k_tr[i], i == 0 ? p.Ep : W, false);
-    if (i == 0 || skip) RC(dw_gemm(p, ws, mt, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_pe), ws.i(p.e_pe), p.Ep, 0, p.Ep, 0, st));
-    if (i > 0) RC(dw_gemm(p, ws, mt, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_h[i - 1]), ws.i(p.e_h[i - 1]), W, 0, W, hoff, st));
-    RC(dw_reduce(p, ws, mt, (size_t)W * p.k_tr[i], gp + p.w_tr[i], st));
+    const DwMat mt = dw_begin(p, rq, W, p.k_tr[i], i == 0 ? p.Ep : W, false);
+    if (i == 0 || skip) RC(dw_gemm(p, mt, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_pe), ws.i(p.e_pe), p.Ep, 0, p.Ep, 0, st));
+    if (i > 0) RC(dw_gemm(p, mt, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_h[i - 1]), ws.i(p.e_h[i - 1]), W, 0, W, hoff, st));
+    RC(dw_reduce(rq, mt, (size_t)W * p.k_tr[i], gp + p.w_tr[i]));
     if (i == 0) break;
     bsp::KcArgs g;
     g.A = dz_cur; g.EA = edz_cur; g.lda = W; g.Ka = W; weights(g, p, pk, p.wj_tt[i]);
     g.I = P; g.J = W; g.K = W; g.C = dz_nxt; g.EC = edz_nxt; g.ldc = W;
     dact(g, p.o_c[i - 1], p.o_h[i - 1], p.e_h[i - 1], W, 0, (i - 1 == 0) ? 30.f : 1.f);
+    cs_ = colsum(g, W);
     RC(bsp::launch_kc(g, st));
-    RC(bias_from_colsum(p, ws, W, gp + p.b_tr[i - 1], st));
+    RC(bias_from_colsum(p, rq, cs_, W, gp + p.b_tr[i - 1]));
     char* t = dz_cur; dz_cur = dz_nxt; dz_nxt = t;
     int* te = edz_cur; edz_cur = edz_nxt; edz_nxt = te;
   }
-  return SNERF_OK;
+  if (rq.over) { set_error("reduction arena too small (plan / pass mismatch)"); return SNERF_ERR_WORKSPACE; }
+  return launch_reductions(rq.elem, rq.col, st);
 }
 
 // weight operand packs of the default arithmetic: table of jobs for bsp::launch_wpack (offsets into the fp32 region)

@@ -62,6 +62,7 @@ struct Plan {
   // backward scratch
   size_t o_dza = 0, o_dzb = 0, o_dsa = 0, o_dsb = 0, o_dsig = 0, o_dfin = 0, o_dsun = 0;
   size_t o_colsum = 0, o_colsum2 = 0, o_slab = 0, o_slab2 = 0, o_skyslab = 0;
+  size_t o_rq = 0, rq_floats = 0;   // reduction arena of the block-scaled plane backward (bsp_pass.hip: per-launch slabs / column-sum partials)
   // ---- block-scaled plane layout (fmt 1; csrc/bsp.h): every activation buffer above holds G16 planes instead of fp32
   //      (same bytes) and has an exponent table; the 32-wide head gradients also exist as planes
   size_t e_pe = 0, e_fa = 0, e_h1 = 0, e_s2 = 0, e_s3 = 0, e_h[SNERF_MAX_LAYERS] = {0};
@@ -90,5 +91,7 @@ DwSplit dw_choose_bsp(int P, int rows, int cols, bool narrow_rows);
 
 // returns SNERF_OK or an error (message via set_error)
 int make_plan(const SnerfDesc* d, Plan* pl);
+
+size_t bsp_rq_floats(const Plan& p);   // bsp_pass.hip
 
 }  // namespace snerf
