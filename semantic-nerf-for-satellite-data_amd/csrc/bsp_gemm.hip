@@ -81,6 +81,7 @@ __device__ __forceinline__ float absmax3(float a, float b, float m) {
 // the sine is bit 0 of k shifted onto the result's sign bit by one v_lshl_add, and the cosine's sign -- (k odd) xor
 // (|r| > pi / 2), the second only at the rounding edge of the reduction -- is the top bit of (k << 31) + bits(pi/2 - |r|),
 // shifted into the byte by v_alignbit.  Arguments beyond 30000 (never with sane data) take sin4_signcos's exact path.
+template <bool SIGNS>
 __device__ __forceinline__ unsigned sin8_signbits(float (&v)[8]) {
   float (&x)[8] = v;
   const float m = absmax3(x[6], x[7], absmax3(x[4], x[5], absmax3(x[2], x[3], absmax3(x[0], x[1], 0.f))));
@@ -116,8 +117,10 @@ __device__ __forceinline__ unsigned sin8_signbits(float (&v)[8]) {
   for (int c = 7; c >= 0; --c) {
     const unsigned kb = __float_as_uint(t[c]);
     v[c] = __uint_as_float((kb << 31) + __float_as_uint(sv[c]));
-    const float edge = 1.57079637f - fabsf(r[c]);
-    byte = __builtin_amdgcn_alignbit(byte, (kb << 31) + __float_as_uint(edge), 31);
+    if (SIGNS) {
+      const float edge = 1.57079637f - fabsf(r[c]);
+      byte = __builtin_amdgcn_alignbit(byte, (kb << 31) + __float_as_uint(edge), 31);
+    }
   }
   return byte;
 }
@@ -152,7 +155,8 @@ constexpr int KC_LDS = KC_TAIL + 128 * 4 + 64 + 64 * 1024;   // one workgroup pe
 constexpr int KC_LDS = KC_TAIL + 128 * 4 + 64;
 #endif
 
-template <int ACT, int AUX, bool COLSUM>
+// SIGNS (ACT_SIN): also produce the sign-of-cos words (training); the forward-only passes skip that arithmetic
+template <int ACT, int AUX, bool COLSUM, bool SIGNS = true>
 __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[KC_LDS];
   int* etab = reinterpret_cast<int*>(lds + KC_TAIL);
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
 #pragma unroll
       for (int c = 0; c < 8; ++c) v[c] = AUX == AUX_SINREC ? x[c] : fmaf(x[c], pre_scale, bj[c]);   // exact power of two, then + bias (SIREN: both times w0)
       if (ACT == ACT_SIN) {
-        sbits |= sin8_signbits(v) << (8 * ps);
+        sbits |= sin8_signbits<SIGNS>(v) << (8 * ps);
       } else if (ACT == ACT_RELU) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
       }
       wmax = fmaxf(wmax, okf * absmax3(v[6], v[7], absmax3(v[4], v[5], absmax3(v[2], v[3], absmax3(v[0], v[1], 0.f)))));
     }
-    if (ACT == ACT_SIN && p.Csign != nullptr && col_ok && rbase < p.I)
+    if (ACT == ACT_SIN && SIGNS && p.Csign != nullptr && col_ok && rbase < p.I)
       p.Csign[((size_t)(rbase >> 5) * ((p.ldc + 63) >> 6) + ((p.c_col0 + j0 + wj0) >> 6)) * 64 + lane] = sbits;
   }
   if (COLSUM && p.colsum != nullptr) {   // one partial row per 128-row tile: the lanes' sums over their 16 rows, then over the 8 row groups
@@ -998,6 +1002,7 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
 #define KC_LAUNCH(ACT_, AUX_, CS_) hipLaunchKernelGGL((gemm_kc_kernel<ACT_, AUX_, CS_>), grid, block, 0, st, a)
   if (a.aux_mode == AUX_SINREC) KC_LAUNCH(ACT_NONE, AUX_SINREC, true);
   else if (a.aux_mode == AUX_RELU_MASK) KC_LAUNCH(ACT_NONE, AUX_RELU_MASK, true);
+  else if (a.act == ACT_SIN && a.Csign == nullptr) hipLaunchKernelGGL((gemm_kc_kernel<ACT_SIN, AUX_NONE, false, false>), grid, block, 0, st, a);
   else if (a.act == ACT_SIN) KC_LAUNCH(ACT_SIN, AUX_NONE, false);
   else if (a.act == ACT_RELU) KC_LAUNCH(ACT_RELU, AUX_NONE, false);
   else if (cs) KC_LAUNCH(ACT_NONE, AUX_NONE, true);

@@ -19,7 +19,8 @@ from tests.helpers import load_fixture, fixture_batch, max_abs, rel_err, check_v
 from tests.test_gpu_pipeline import _pipeline_for, _batch_to_dev, DEV, OUT_TOL, LOSS_RTOL, GRAD_REL_TOL
 
 pytestmark = pytest.mark.gpu
-ROW_TOL = 2e-4      # per-ray gradient rows down to 2^-20 of the loudest ray (test_heavy_tailed_gradients)
+ROW_TOL = 4e-6      # per-ray gradient rows down to 2^-20 of the loudest ray (test_heavy_tailed_gradients): measured 3.9e-7 with
+                    # per-block exponents (round 1's per-tensor scales: 1.2e-4 on the rows at the floor)
 
 
 def _rand_sequence(monkeypatch, tensors):
@@ -355,7 +356,7 @@ def test_heavy_tailed_gradients():
     orders of magnitude: near-opaque rays next to almost empty ones) and per-ray loss weights from 1 down to 1e-9 (a few
     loud rays among thousands of almost-silent ones), at the headline width.  Required: every parameter gradient within
     2e-3 relative L2 of the fp32 oracle, and the PER-RAY input gradient d loss / d t (the rows of dX of the head layer,
-    summed over a ray's samples) of every ray down to 2^-20 of the loudest within 1e-4 relative of the oracle -- i.e. a
+    summed over a ray's samples) of every ray down to 2^-20 of the loudest within 4e-6 relative of the oracle -- i.e. a
     silent ray's gradient row keeps its own precision next to a loud one."""
     from tests.test_gpu_kernels import _gpu_params, _hip_render, _dev
     dev = _dev()
@@ -409,7 +410,8 @@ def test_heavy_tailed_gradients():
     live = row >= row.max() * 2.0 ** -20
     assert int(live.sum()) >= 40
     row_err = (dt_h - dt_o).norm(dim=1)[live] / row[live]
-    # measured with per-TENSOR operand scales (round 1): median 3e-7, 1.2e-4 on the rows right at the 2^-20 floor
+    # per-(128 x 128)-block exponents: max 3.9e-7, median 2.0e-7 (per-tensor scales, round 1: 1.2e-4 on the rows at the floor)
+    print("heavy-tail per-ray gradient rows: max rel err %.3g, median %.3g over %d live rows" % (float(row_err.max()), float(row_err.median()), int(live.sum())))
     assert float(row_err.max()) <= ROW_TOL, (float(row_err.max()), float(row_err.median()))
     # rays outside the subset got exactly zero
     mask = torch.ones(N, dtype=torch.bool)
