@@ -177,6 +177,15 @@ int snerf_forward(const SnerfDesc* desc, const float* packed_params, const Snerf
  * z_steps (S) and an optional jitter tensor u (N,S).  Lets a caller share one z between passes on different streams. */
 int snerf_sample_z(const float* rays, const float* z_steps, const float* u, float* z, int n_rays, int n_samples, void* stream);
 
+/* The per-ray embedding rows (nn.Embedding(50, tau) indexed by the rays' image index `ts`:
+ * semantic/components/rendering.py:35-46, baseline/components/rendering.py:29-40).
+ * snerf_embedding_rows: rows[n][:] = table[idx[n]][:]  (forward; idx is int64 as torch hands it over).
+ * snerf_embedding_backward: grad_table[v][:] += sum over the rays n with idx[n] == v of d_rows[n][:], summed in a fixed
+ * order (no atomics: the gradient is bitwise reproducible, like every other one of the path).  Indices outside
+ * [0, n_embed) give zero rows in the forward and are skipped in the backward (torch's nn.Embedding asserts on the device). */
+int snerf_embedding_rows(const float* table, int n_embed, int tau, const long long* idx, int n, float* rows, void* stream);
+int snerf_embedding_backward(const long long* idx, const float* d_rows, int n, int tau, int n_embed, float* grad_table, void* stream);
+
 /* Backward of one pass (what autograd does in the reference for the ops above): consumes the
  * activations that snerf_forward(SNERF_FLAG_TRAIN) left in `workspace`, ACCUMULATES parameter
  * gradients into packed_grads (caller zeroes it once per step) and writes d loss / d t (N,tau)

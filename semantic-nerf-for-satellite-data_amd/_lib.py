@@ -150,6 +150,10 @@ def lib():
                                     C.c_void_p, C.POINTER(SnerfLossGrads), C.c_void_p]
     L.snerf_sample_z.restype = C.c_int
     L.snerf_sample_z.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.snerf_embedding_rows.restype = C.c_int
+    L.snerf_embedding_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.snerf_embedding_backward.restype = C.c_int
+    L.snerf_embedding_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.snerf_adam_step.restype = C.c_int
     L.snerf_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_ulonglong, C.c_float, C.c_float,
                                   C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]
@@ -171,4 +175,4 @@ EXPORTED_SYMBOLS = ("snerf_version", "snerf_last_error", "snerf_packed_floats", 
                     "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward", "snerf_test_gemm",
                     "snerf_loss_workspace_bytes", "snerf_loss_partial", "snerf_loss_finish", "snerf_profile_begin",
                     "snerf_profile_end", "snerf_sample_z", "snerf_adam_step", "snerf_test_bsp_roundtrip", "snerf_test_bsp_kc",
-                    "snerf_test_bsp_dw")
+                    "snerf_test_bsp_dw", "snerf_embedding_rows", "snerf_embedding_backward")

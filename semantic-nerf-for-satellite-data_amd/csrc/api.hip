@@ -755,6 +755,16 @@ int snerf_sample_z(const float* rays, const float* z_steps, const float* u, floa
   return launch_sample_z(rays, z_steps, u, z, n_rays, n_samples, (hipStream_t)stream);
 }
 
+int snerf_embedding_rows(const float* table, int n_embed, int tau, const long long* idx, int n, float* rows, void* stream) {
+  if (!table || !idx || !rows || n_embed <= 0 || tau <= 0 || n <= 0) { set_error("snerf_embedding_rows: bad argument"); return SNERF_ERR_NULL; }
+  return launch_embedding_rows(table, n_embed, tau, idx, n, rows, (hipStream_t)stream);
+}
+
+int snerf_embedding_backward(const long long* idx, const float* d_rows, int n, int tau, int n_embed, float* grad_table, void* stream) {
+  if (!idx || !d_rows || !grad_table || n_embed <= 0 || tau <= 0 || n <= 0) { set_error("snerf_embedding_backward: bad argument"); return SNERF_ERR_NULL; }
+  return launch_embedding_backward(idx, d_rows, n, tau, n_embed, grad_table, (hipStream_t)stream);
+}
+
 int snerf_profile_begin(void) { return profile_begin(); }
 int snerf_profile_end(SnerfProfile* out) { return profile_end(out); }
 

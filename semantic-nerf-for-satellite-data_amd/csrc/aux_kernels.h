@@ -39,6 +39,8 @@ int red_add_col(RedTable& tb, const float* in, int n_in, size_t stride, int widt
 int launch_reductions(const RedTable& elem, const RedTable& col, hipStream_t st);
 int colsum32_blocks(int rows);   // partial rows launch_colsum32 writes
 int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st);
+int launch_embedding_rows(const float* table, int n_embed, int tau, const long long* idx, int n, float* rows, hipStream_t st);
+int launch_embedding_backward(const long long* idx, const float* d_rows, int n, int tau, int n_embed, float* grad, hipStream_t st);
 int launch_ray_sum(const float* dfa, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st);
 
 }  // namespace snerf

@@ -248,6 +248,47 @@ int reduce_partials(const float* in, int n_in, size_t in_stride, int width, floa
   return 0;
 }
 
+// ---- per-ray embedding rows ---------------------------------------------------------------------------------------
+__global__ void embedding_rows_kernel(const float* __restrict__ table, int n_embed, int tau, const long long* __restrict__ idx,
+                                      int n, float* __restrict__ rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * tau) return;
+  const int r = i / tau, c = i - r * tau;
+  const long long v = idx[r];
+  if (v < 0 || v >= n_embed) { rows[i] = 0.f; return; }
+  rows[i] = table[(size_t)v * tau + c];
+}
+// one workgroup per table row v: thread t adds the rays t, t + 256, ... that index v (ascending), then the 256 partial
+// sums are added in thread order -- a fixed summation order for any ray permutation of the same batch order
+__global__ __launch_bounds__(256) void embedding_backward_kernel(const long long* __restrict__ idx, const float* __restrict__ d_rows,
+                                                                 int n, int tau, float* __restrict__ grad) {
+  __shared__ float part[256];
+  const long long v = blockIdx.x;
+  for (int c = 0; c < tau; ++c) {
+    float s = 0.f;
+    for (int r = threadIdx.x; r < n; r += 256)
+      if (idx[r] == v) s += d_rows[(size_t)r * tau + c];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float a = 0.f;
+      for (int t = 0; t < 256; ++t) a += part[t];
+      grad[(size_t)v * tau + c] += a;
+    }
+    __syncthreads();
+  }
+}
+int launch_embedding_rows(const float* table, int n_embed, int tau, const long long* idx, int n, float* rows, hipStream_t st) {
+  hipLaunchKernelGGL(embedding_rows_kernel, dim3((n * tau + 255) / 256), dim3(256), 0, st, table, n_embed, tau, idx, n, rows);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+int launch_embedding_backward(const long long* idx, const float* d_rows, int n, int tau, int n_embed, float* grad, hipStream_t st) {
+  hipLaunchKernelGGL(embedding_backward_kernel, dim3(n_embed), dim3(256), 0, st, idx, d_rows, n, tau, grad);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- batched reductions: every slab / column-sum reduction of a backward pass in TWO launches ------------------------
 // out[e] += sum_{q < n_in} in[q * stride + e]; job tables travel as kernel arguments.  Fixed order -> deterministic.
 // "elem" jobs (dW split slabs: few rows, many elements): a thread owns four consecutive elements (or one, `vec` = 0) and

@@ -428,6 +428,44 @@ def render_pass_into(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Te
     return workspace
 
 
+class _EmbedRows(torch.autograd.Function):
+    """rows = table[idx] with the library's deterministic backward (snerf_embedding_rows / snerf_embedding_backward)."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        L = _lib.lib()
+        _check_dev(table, "embedding table")
+        tb = table.detach().contiguous()
+        ix = idx.contiguous()
+        rows = torch.empty((ix.shape[0], tb.shape[1]), dtype=torch.float32, device=tb.device)
+        with torch.cuda.device(tb.device):
+            _lib.check(L.snerf_embedding_rows(_ptr(tb), tb.shape[0], tb.shape[1], _ptr(ix), ix.shape[0], _ptr(rows), _stream()),
+                       "snerf_embedding_rows")
+        ctx.save_for_backward(ix)
+        ctx.shape = tuple(tb.shape)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        (ix,) = ctx.saved_tensors
+        L = _lib.lib()
+        grad = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        gc = g.contiguous()
+        with torch.cuda.device(g.device):
+            _lib.check(L.snerf_embedding_backward(_ptr(ix), _ptr(gc), ix.shape[0], ctx.shape[1], ctx.shape[0], _ptr(grad), _stream()),
+                       "snerf_embedding_backward")
+        return grad, None
+
+
+def embed_rows(embedding: torch.nn.Module, idx: torch.Tensor) -> torch.Tensor:
+    """models["t"](ts) of the reference renderers (semantic/components/rendering.py:35-46): the rays' rows of an
+    nn.Embedding.  torch's embedding backward is a sort + segmented-scatter chain of ~12 launches; here forward and
+    backward are one launch each, the backward summed in a fixed order."""
+    if idx.dtype != torch.int64:
+        idx = idx.long()
+    return _EmbedRows.apply(embedding.weight, idx)
+
+
 def sample_z(rays: torch.Tensor, z_steps: torch.Tensor, u: torch.Tensor | None) -> torch.Tensor:
     """stratified depths (N,S) -- snerf_sample_z"""
     L = _lib.lib()

@@ -1,8 +1,8 @@
 """Semantic renderer -- mirror of semantic/components/rendering.py:12-80 (RSSemanticRendering).
 
 ts -> int64 happens on the device (the reference round-trips through a CPU LongTensor, :35-40; same
-values), the embedding lookup stays a torch op (its scatter-add backward gives the nn.Embedding
-gradient), and both passes -- main and, if sc_lambda > 0, the solar-correction pass on o + sun_d*z --
+values), the embedding lookup is ops.embed_rows (one launch forward, one deterministic launch backward
+for the nn.Embedding gradient), and both passes -- main and, if sc_lambda > 0, the solar-correction pass on o + sun_d*z --
 run as fused HIP passes that share one packed copy of the weights."""
 import os
 
@@ -38,8 +38,8 @@ def fused_model_rendering(renderer, models, typ, rays, extras, render_options, i
     opts = render_options or {}
     sun_d = extras_component_fn(extras, "sun_d")
     ts = extras_component_fn(extras, "ts").squeeze(-1).long()
-    rays_t = models["t"](ts)
-    rays_t_s = models["t_s"](ts) if "t_s" in models else None
+    rays_t = ops.embed_rows(models["t"], ts)
+    rays_t_s = ops.embed_rows(models["t_s"], ts) if "t_s" in models else None
     model = models[typ]
     params = dict(model.named_parameters())
     packed = opts.get("packed_params")
@@ -92,8 +92,8 @@ def fused_model_rendering_into(renderer, models, typ, rays, extras, render_optio
     opts = render_options or {}
     sun_d = extras_component_fn(extras, "sun_d")
     ts = extras_component_fn(extras, "ts").squeeze(-1).long()
-    rays_t = models["t"](ts)
-    rays_t_s = models["t_s"](ts) if "t_s" in models else None
+    rays_t = ops.embed_rows(models["t"], ts)
+    rays_t_s = ops.embed_rows(models["t_s"], ts) if "t_s" in models else None
     model = models[typ]
     params = dict(model.named_parameters())
     packed = opts.get("packed_params")

@@ -417,3 +417,28 @@ def test_heavy_tailed_gradients():
     mask = torch.ones(N, dtype=torch.bool)
     mask[idx] = False
     assert float(t_g.grad.cpu()[mask].abs().max()) == 0.0
+
+
+def test_embedding_rows_forward_backward():
+    """ops.embed_rows == nn.Embedding (reference: models["t"](ts), semantic/components/rendering.py:35-46): rows bit-equal,
+    the table gradient equal to torch's scatter-add to fp32 summation order, and bit-identical from run to run."""
+    from snerf_amd import ops
+    torch.manual_seed(7)
+    emb = torch.nn.Embedding(50, 4).to(DEV)
+    ref = torch.nn.Embedding(50, 4).to(DEV)
+    ref.load_state_dict(emb.state_dict())
+    idx = torch.randint(0, 50, (4099,), device=DEV)
+    idx[:7] = 49
+    w = torch.randn(4099, 4, device=DEV)
+    rows = ops.embed_rows(emb, idx)
+    want = ref(idx)
+    assert torch.equal(rows, want)
+    (rows * w).sum().backward()
+    (want * w).sum().backward()
+    g1 = emb.weight.grad.clone()
+    assert max_abs(g1.cpu(), ref.weight.grad.cpu()) <= 1e-5 * float(ref.weight.grad.abs().max())
+    emb.weight.grad = None
+    (ops.embed_rows(emb, idx) * w).sum().backward()
+    assert torch.equal(emb.weight.grad, g1)
+    # float indices as the extras column carries them (rays' image index), through the renderer's own conversion
+    assert torch.equal(ops.embed_rows(emb, idx.float().long()), want)
