@@ -155,6 +155,37 @@ def unregister_grad_sinks(params):
         _GRAD_SINKS.pop(id(p), None)
 
 
+def wait_grad_sinks(device=None):
+    """Make the current stream wait for the last accumulating unpack.  A pass that writes sinks hands autograd no parameter
+    gradients, so the engine's end-of-backward stream synchronisation (which follows AccumulateGrad) does not cover the
+    side stream of the solar-correction pass: every consumer of the sink tensors calls this first (FlatAdam does)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ev = _SINK_EVENT.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    if ev is not None:
+        torch.cuda.current_stream(dev).wait_event(ev)
+
+
+_SINK_SYNC_QUEUED: set = set()
+
+
+def _queue_sink_sync(dev):
+    """Once per backward(): when the whole graph has run, the stream that called backward() waits for the last sink write
+    (autograd's own end-of-backward synchronisation only follows AccumulateGrad nodes, which the sink path bypasses)."""
+    key = dev.index
+    if key in _SINK_SYNC_QUEUED:
+        return
+
+    def _cb():
+        _SINK_SYNC_QUEUED.discard(key)
+        wait_grad_sinks(dev)
+
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_cb)
+        _SINK_SYNC_QUEUED.add(key)
+    except RuntimeError:      # not inside a backward pass of the engine (direct call): the consumer synchronises
+        pass
+
+
 def _sinks_for(params):
     if not _SINKS_ON or not _GRAD_SINKS:
         return None
@@ -354,6 +385,7 @@ class _RenderPass(torch.autograd.Function):
                 ev = torch.cuda.Event()
                 ev.record(st)
                 _SINK_EVENT[dev.index] = ev
+            _queue_sink_sync(dev)
             return (None, None, None, None, None, None, d_t, d_ts) + (None,) * len(ctx.names)
         grads = unpack_grads(spec, pg, like)
         # EVERY parameter gets a gradient tensor, zero where no result gradient reaches it: the reference's model returns

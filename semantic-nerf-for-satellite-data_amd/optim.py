@@ -99,6 +99,9 @@ class FlatAdam:
         all-reduce stays one call, and step() skips it as torch.optim.Adam does."""
         if self._active is not None:      # already gathered for this step (TrainLoop calls this before the all-reduce)
             return
+        if self.sinks:
+            from . import ops
+            ops.wait_grad_sinks(self.flat_g.device)   # the sc pass accumulates on its own stream
         src, dst, active = [], [], []
         touched = None
         if self.sinks and getattr(self, "_none_mode", True):
