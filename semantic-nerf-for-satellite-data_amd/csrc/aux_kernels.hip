@@ -124,7 +124,7 @@ __global__ void copy_table_kernel(CopyTable tb, float* __restrict__ packed, int 
 
 int launch_copy_table(const CopyTable& tb, float* packed, int mode, hipStream_t st) {
   if (tb.n <= 0) return 0;
-  hipLaunchKernelGGL(copy_table_kernel, dim3(tb.n, 8), dim3(256), 0, st, tb, packed, mode);
+  hipLaunchKernelGGL(copy_table_kernel, dim3(tb.n, 64), dim3(256), 0, st, tb, packed, mode);   // 64 workgroups per tensor: the 512 x 512 ones are 1 MB each
   SNERF_LAUNCH_CHECK();
   return 0;
 }
