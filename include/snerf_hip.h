@@ -47,10 +47,12 @@ extern "C" {
 
 /* Arithmetic of the dense contractions.  With NONE of the arithmetic bits set a pass runs the default, SNERF_FLAG_F16X2
  * (the same for C and Python callers); the other bits select the alternatives and exclude each other. */
-#define SNERF_FLAG_F16X2 64u   /* DEFAULT (flags = 0 means this): fp32-class arithmetic on the fp16 matrix cores.  Every operand
-                                  is scaled by a power of two, split into two fp16 planes (22 significant bits) and contracted
-                                  as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation; the dropped
-                                  lo*lo term is 2^-22 relative, below an fp32 GEMM's own rounding (normwise) */
+#define SNERF_FLAG_F16X2 64u   /* DEFAULT (flags = 0 means this): fp32-class arithmetic on the fp16 matrix cores.  Every activation
+                                  tensor of the workspace is two fp16 planes (22 significant bits) with one power-of-two exponent
+                                  per 128 x 128 block, written once by the producing kernel; a product is hi*hi + hi*lo + lo*hi on
+                                  v_mfma_f32_32x32x16_f16 with fp32 accumulation; the dropped lo*lo term is 2^-22 relative, below
+                                  an fp32 GEMM's own rounding (normwise).  Needs fc_units % 32 == 0, feat_last % 16 == 0 and
+                                  3 + t_dim (x2 with a separate t_s) <= 16: other shapes return SNERF_ERR_BAD_DESC */
 #define SNERF_FLAG_SPLIT3 128u /* fp32-class, conservative: three bf16 planes per fp32 operand (24 significant bits whatever the
                                   magnitude), six v_mfma_f32_32x32x16_bf16 products, fp32 accumulate; twice the matrix work of
                                   the default */
@@ -157,8 +159,9 @@ size_t snerf_workspace_bytes(const SnerfDesc* desc);
 /* ---- parameter packing ------------------------------------------------------------------------- */
 /* Gather the state_dict tensors into the padded, MFMA-friendly packed layout (DESIGN.md "Data layout").
  * Replaces nothing in the reference (torch.nn.Linear owns its layout there); run once per optimiser step.
- * The pre-split weight planes inside the buffer follow desc->flags' arithmetic (bf16 planes, or fp16 planes with each
- * matrix's |max| slots under SNERF_FLAG_F16X2): pack, forward and backward must use the same arithmetic flags. */
+ * The pre-split weight operands inside the buffer follow desc->flags' arithmetic (k-tile-major bf16 planes under the
+ * arithmetic flags; fragment-ordered fp16 planes + one exponent per matrix in the default arithmetic): pack, forward and
+ * backward must use the same arithmetic flags. */
 int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* packed, void* stream);
 /* Scatter packed gradients back into tensors shaped like the parameters (overwrite, or add if accumulate). */
 int snerf_unpack_grads(const SnerfDesc* desc, const float* packed_grads, const SnerfParams* grads,

@@ -365,8 +365,9 @@ def test_full_size_properties_headline_config():
     assert all(torch.equal(r1[k], r2[k]) for k in r1), "forward is not bit-reproducible"
     assert g1.keys() == g2.keys() and all(torch.equal(g1[n], g2[n]) for n in g1), "gradients are not bit-reproducible"
     assert all(torch.isfinite(g).all() for g in g1.values())
-    # permutation equivariance (exact: every ray's arithmetic is independent of its position in the batch, up to the
-    # per-tensor operand scales, which are permutation-invariant maxima)
+    # permutation equivariance (exact: every ray's arithmetic is independent of its position in the batch; the block
+    # exponents of the plane format depend on a block's neighbours, but a power-of-two scale does not change how a value
+    # rounds to fp16 planes -- floating point -- as long as it stays in fp16's normal range)
     perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(DEV)
     rp = run(rays[perm], extras[perm], u[perm], False)
     rn = run(rays, extras, u, False)
@@ -380,8 +381,8 @@ def test_full_size_properties_headline_config():
     assert bool((rn["depth_coarse"] <= rays[:, 7] + 1e-4).all()) and bool((rn["depth_coarse"] >= -1e-6).all())
     assert torch.equal(rn["semantic_label_coarse"], rn["semantic_logits_coarse"].argmax(1))
     assert float(rn["rgb_coarse"].min()) >= -1e-5 and torch.isfinite(rn["rgb_coarse"]).all()
-    # chunk invariance: halves rendered separately vs together differ only through the per-tensor operand scale
-    # (a power of two taken from each chunk's own maximum), i.e. by fp32 rounding
+    # chunk invariance: halves rendered separately vs together may differ only where a block exponent pushes a lo-plane
+    # value into fp16's subnormal range, i.e. far below fp32 rounding
     h = N // 2
     ra, rb_ = run(rays[:h], extras[:h], u[:h], False), run(rays[h:], extras[h:], u[h:], False)
     for k in ("rgb_coarse", "depth_coarse", "weights_coarse"):
