@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
   const bool X6 = argc > 1 && argv[1][0] == 'x';
   const int PLANES = argc > 2 ? atoi(argv[2]) : 3;
   const int TILE = argc > 3 ? atoi(argv[3]) : 0;
-  const int FMT = argc > 4 ? atoi(argv[4]) : 0;
+  (void)(argc > 4 ? atoi(argv[4]) : 0);   // (former operand-format switch: the fp16-plane arithmetic now lives in bsp_gemm.hip, see build_one.sh)
   const int P = 262144, W = 512;
   float *X, *Wt, *Y, *Y2, *dW, *cs;
   CK(hipMalloc(&X, (size_t)P * W * 4)); CK(hipMalloc(&Wt, (size_t)W * W * 4)); CK(hipMalloc(&Y, (size_t)P * W * 4));
@@ -41,34 +41,34 @@ int main(int argc, char** argv) {
       if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; } }
     else { g.A = X; g.lda = W; g.a_ic = true; g.B = Y2; g.ldb = W; g.b_ic = true; g.I = W; g.J = W; g.K = P; g.C = dW; g.ldc = W;
       g.k_split = ((P + 63) / 64 + 31) / 32 * 32; g.n_split = (P + g.k_split - 1) / g.k_split; g.slab_stride = (size_t)W * W; }
-    g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
+    g.x6 = X6; g.planes = PLANES; g.tile = TILE;
     double t = time_gemm(g, 12); printf("only-mode %d: %.3f ms\n", atoi(argv[6]), t);
     return 0;
   }
-  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
+  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
     time_gemm(g, 400); }  // clock / power state warm-up
-  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
+  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
     if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; }
     double t = time_gemm(g, 20); printf("fwd plain        %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.bias = Wt; g.act = ACT_SIN; g.w0 = 1.f;
     t = time_gemm(g, 20); printf("fwd sin          %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.C2 = Y2;
     t = time_gemm(g, 20); printf("fwd sin+cos out  %.3f ms %.1f TF\n", t, fl / t / 1e9); }
-  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.b_ic = true; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
+  { GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.b_ic = true; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
     double t = time_gemm(g, 20); printf("dX plain         %.3f ms %.1f TF\n", t, fl / t / 1e9);
     g.aux = Y2; g.ldaux = W; g.aux_mode = AUX_MUL; g.colsum = cs; g.ldcs = W;
     t = time_gemm(g, 20); printf("dX aux+colsum    %.3f ms %.1f TF\n", t, fl / t / 1e9); }
-  for (int ns : {32, 48, 64, 128}) { GemmArgs g; g.A = X; g.lda = W; g.a_ic = true; g.B = Y2; g.ldb = W; g.b_ic = true; g.I = W; g.J = W; g.K = P; g.C = dW; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
+  for (int ns : {32, 48, 64, 128}) { GemmArgs g; g.A = X; g.lda = W; g.a_ic = true; g.B = Y2; g.ldb = W; g.b_ic = true; g.I = W; g.J = W; g.K = P; g.C = dW; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
     g.k_split = ((P + ns - 1) / ns + 31) / 32 * 32; g.n_split = (P + g.k_split - 1) / g.k_split; g.slab_stride = (size_t)W * W;
     double t = time_gemm(g, 20); printf("dW split %d      %.3f ms %.1f TF\n", ns, t, fl / t / 1e9); }
   for (int div : {1, 2, 4, 8, 16}) {  // size sweep: fixed per-launch cost?
-    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P / div; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
+    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P / div; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
     if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; }
     double t = time_gemm(g, 40); printf("fwd plain I=P/%-2d  %.3f ms %.1f TF\n", div, t, fl / div / t / 1e9);
   }
 #ifdef SNERF_ABL_CLOCK
   {  // per-workgroup phase cycles of the split kernel (colsum doubles as the stamp buffer; the epilogue skips colsum under CLOCK)
-    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE; g.fmt = FMT;
+    GemmArgs g; g.A = X; g.lda = W; g.B = Wt; g.ldb = W; g.I = P; g.J = W; g.K = W; g.C = Y; g.ldc = W; g.x6 = X6; g.planes = PLANES; g.tile = TILE;
     if (X6) { g.Bpl = Bplanes; g.pl_stride = (size_t)W * W; g.bt_rows = W; g.bt_elems = (size_t)W * W; }
     if (argc <= 5 || atoi(argv[5]) != 0) { g.bias = Wt; g.act = ACT_SIN; g.w0 = 1.f; }
     unsigned long long* dbg; const int nb = (P / 128) * (W / 128);
