@@ -841,20 +841,34 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
     const int grp = wave >> 2;
     f16x8 fa_h[4], fa_l[4], fb_h[2], fb_l[2];
     auto phaseM = [&](int s, int slot) {
+#ifndef BSP_ABL_DW_NODMA
       issue(s + 2, (slot + 2) % 3);
+#endif
       chunk(s);
       const char* st = lds + slot * T::STAGE;
+#ifdef BSP_ABL_DW_NOLDSREAD
+      const f16x8 cst = __builtin_bit_cast(f16x8, u32x4{(unsigned)s, 1u, 2u, (unsigned)(size_t)st});
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) { fb_h[nj] = cst; fb_l[nj] = cst; }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) { fa_h[mi] = cst; fa_l[mi] = cst; }
+#else
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) { fb_h[nj] = trfrag(st, foB[nj][0], 1024); fb_l[nj] = trfrag(st, foB[nj][1], 1024); }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) { fa_h[mi] = trfrag(st, foA[mi][0], PA); fa_l[mi] = trfrag(st, foA[mi][1], PA); }
+#endif
     };
     auto phaseC = [&]() {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
+#ifdef BSP_ABL_DW_NOMFMA
+        asm volatile("" ::"v"(fa_h[mi]), "v"(fa_l[mi]), "v"(fb_h[0]), "v"(fb_l[0]), "v"(fb_h[1]), "v"(fb_l[1]));
+#else
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = mfma3(fa_h[mi], fa_l[mi], fb_h[nj], fb_l[nj], acc[mi][nj]);
+#endif
       __builtin_amdgcn_s_setprio(0);
     };
     wait_vm<NPIECE>();          // stage 0 (own pieces); stage 1 stays in flight
