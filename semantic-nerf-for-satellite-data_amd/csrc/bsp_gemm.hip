@@ -156,17 +156,31 @@ constexpr int KC_LDS = KC_TAIL + 128 * 4 + 64;
 #endif
 
 // SIGNS (ACT_SIN): also produce the sign-of-cos words (training); the forward-only passes skip that arithmetic
+// BSP_ABL_PAIR (ablation build): ONE workgroup of eight waves runs TWO row-adjacent 128 x 256 tiles (waves 0-3 / 4-7, one
+// LDS ring each) behind common barriers, so that the two waves of a SIMD stay in the same phase (loop beside loop,
+// epilogue beside epilogue) instead of drifting through every phase pairing.  Measured 459 / 515 us against 407 / 428 for
+// two independent workgroups: what the product gains from co-residency is exactly the loop-beside-epilogue pairing.
+#ifdef BSP_ABL_PAIR
+constexpr int KC_HALVES = 2;
+#else
+constexpr int KC_HALVES = 1;
+#endif
+constexpr int KC_LDS_R = (KC_LDS + 255) & ~255;
 template <int ACT, int AUX, bool COLSUM, bool SIGNS = true>
-__global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[KC_LDS];
+__global__ __launch_bounds__(256 * KC_HALVES, KC_HALVES == 2 ? 1 : 2) void gemm_kc_kernel(const KcArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds_all[KC_HALVES * KC_LDS_R];
+  const int t = threadIdx.x, lane = t & 63;
+  const int half = KC_HALVES == 2 ? __builtin_amdgcn_readfirstlane(t >> 8) : 0;
+  char* const lds = lds_all + half * KC_LDS_R;
   int* etab = reinterpret_cast<int*>(lds + KC_TAIL);
   float* smax = reinterpret_cast<float*>(lds + KC_TAIL + 512);
 
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((t >> 6) & 3);
   const int wj0 = wave * 64;
   int ti, tj;
-  tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);
+  tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);   // tiles_i counts row-tile PAIRS in the paired build
+  ti = KC_HALVES * ti + half;
+  const int ti_e = min(ti, (p.I + 127) / 128 - 1);            // exponent-table row of a tile beyond I (its results are never stored)
   const int i0 = ti * 128, j0 = tj * 256;
   const int nks = p.K >> 4, nks1 = p.Ka >> 4;
 #ifdef BSP_ABL_STAMP
@@ -236,11 +250,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   // ---- exponents along k: table in LDS + a bit per step where the scale changes (128 steps at most: K <= 2048).
   // The loads go out first and are consumed behind the first stage requests (their wait then counts past the DMA).
   const int sA = lane, sB = lane + 64;
-  const int eA = sA < nks ? kc_exp_of_step(p, ti, sA, nks1) : 0;
-  const int eB = sB < nks ? kc_exp_of_step(p, ti, sB, nks1) : 0;
-  const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti, sA - 1, nks1) : eA;
-  const int eBp = sB < nks ? kc_exp_of_step(p, ti, sB - 1, nks1) : eB;
-  const int e_last = kc_exp_of_step(p, ti, nks - 1, nks1);
+  const int eA = sA < nks ? kc_exp_of_step(p, ti_e, sA, nks1) : 0;
+  const int eB = sB < nks ? kc_exp_of_step(p, ti_e, sB, nks1) : 0;
+  const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti_e, sA - 1, nks1) : eA;
+  const int eBp = sB < nks ? kc_exp_of_step(p, ti_e, sB - 1, nks1) : eB;
+  const int e_last = kc_exp_of_step(p, ti_e, nks - 1, nks1);
   // Both operands are requested ahead: W two sub-steps, A two stages.  vm-counter order: [W(0) A(0) x 4] [W(1) A(1) x 4],
   // then per sub-step s = 2 S + u: [W(s + 2) x 4] [two pieces of A(S + 2)] -- at the top of sub-step s the six requests
   // of sub-step s - 1 may be outstanding and everything older has landed, which covers W(s) and all of stage S (issued
@@ -423,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   float val[4][4][8];
   float wmax = 0.f;
   int eH = 0;
-  if (AUX != AUX_NONE && j0 + wj0 < p.J) eH = p.EH[(size_t)ti * ncb_of(p.ldh) + ((p.h_col0 + j0 + wj0) >> 7)];
+  if (AUX != AUX_NONE && j0 + wj0 < p.J) eH = p.EH[(size_t)ti_e * ncb_of(p.ldh) + ((p.h_col0 + j0 + wj0) >> 7)];
   const float inv_h = pow2f(-eH);
   const size_t offH = uniform_sz(((size_t)i0 * p.ldh + p.h_col0) * 4);
   const srd_t srdH = make_srd(AUX != AUX_NONE ? p.H + offH : nullptr, AUX != AUX_NONE ? 0xFFFFFFE0u : 0u);
@@ -531,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
     for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
       for (int c = 0; c < 8; ++c) cs[c] += __shfl_xor(cs[c], o, 64);
-    if (lane < 8 && col_ok) {
+    if (lane < 8 && col_ok && i0 < p.I) {
       float* d = p.colsum + (size_t)ti * p.ldcs + col;
       *reinterpret_cast<float4*>(d) = make_float4(cs[0], cs[1], cs[2], cs[3]);
       *reinterpret_cast<float4*>(d + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
@@ -551,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   const float bmax = fmaxf(smax[wave & 2], smax[(wave & 2) + 1]);
   const int eC = exp_of_maxbits(__float_as_uint(bmax));
   const float sc = pow2f(eC);
-  if ((wave & 1) == 0 && lane == 0 && j0 + wj0 < p.J) p.EC[(size_t)ti * ncb_of(p.ldc) + ((p.c_col0 + j0 + wj0) >> 7)] = eC;
+  if ((wave & 1) == 0 && lane == 0 && j0 + wj0 < p.J && i0 < p.I) p.EC[(size_t)ti * ncb_of(p.ldc) + ((p.c_col0 + j0 + wj0) >> 7)] = eC;
   const size_t offC = uniform_sz(((size_t)i0 * p.ldc + p.c_col0) * 4);
   const srd_t srdC = make_srd(p.C + offC, 0xFFFFFFE0u);
   // quad exchange: lanes 0, 1 of a quad hold group m (hi and lo planes of columns 0-7 / 8-15), lanes 2, 3 group m + 2.
@@ -1008,9 +1022,9 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   if (!a.A2) { a.A2 = a.A; a.EA2 = a.EA; a.lda2 = a.lda; a.a2_col0 = a.a_col0; if (a.Ka == 0) a.Ka = a.K; }
   int rc = check_kc(a, false);
   if (rc) return rc;
-  a.tiles_i = (a.I + 127) / 128;
+  a.tiles_i = ((a.I + 127) / 128 + KC_HALVES - 1) / KC_HALVES;
   a.tiles_j = (a.J + 255) / 256;
-  const dim3 grid(a.tiles_i * a.tiles_j), block(256);
+  const dim3 grid(a.tiles_i * a.tiles_j), block(256 * KC_HALVES);
   const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.K, 0, st);
   const bool cs = a.colsum != nullptr;
 #define KC_LAUNCH(ACT_, AUX_, CS_) hipLaunchKernelGGL((gemm_kc_kernel<ACT_, AUX_, CS_>), grid, block, 0, st, a)
