@@ -14,8 +14,8 @@
 //     v_mfma_f32_32x32x16_f16 (dropped lo lo term: 2^-22 relative) and, where the exponent changes along its
 //     contraction axis, rescales its fp32 accumulators by the power of two (exact).
 // Weights are packed once per step in MFMA fragment order ("WF16": 2 KiB units of 32 rows x 16 k = [plane][lane][16 B],
-// lane = 32 (k / 8) + row: one fragment is one contiguous KiB that a wave loads straight into registers) with one
-// exponent per matrix.
+// lane = 32 (k / 8) + slot, slot m holding row wf16_row(m) of the unit: one fragment is one contiguous KiB that a wave
+// loads straight into registers) with one exponent per matrix.
 #pragma once
 #include "common.h"
 #include "gemm.h"
@@ -77,6 +77,14 @@ __device__ __forceinline__ void join8(const u32x4 hi, const u32x4 lo, float inv_
 #pragma unroll
   for (int i = 0; i < 8; ++i) x[i] = fmaf((float)h[i], inv_scale, (float)l[i] * inv_scale);   // two v_fma_mix_f32; exact (power of two)
 }
+
+// Row order inside a 32-row unit of a WF16 weight pack: MFMA row m of the unit holds matrix row (unit base) + wf16_row(m),
+// bits 2 and 3 of m exchanged (an involution).  The K-contiguous kernel uses the weights as the matrix cores' A operand,
+// so the accumulator of lane l holds, for ONE point (l & 31), the output columns m = (r & 3) + 8 (r >> 2) + 4 (l >> 5) of
+// the unit; with this order those are columns 16 (r >> 3) + 8 (l >> 5) + (r & 7): two runs of eight consecutive
+// columns = one 16-byte piece of each plane per 16-column group, stored (and, for the derivative epilogues, loaded)
+// without any exchange between lanes.
+__host__ __device__ inline int wf16_row(int m) { return (m & 0x13) | ((m & 4) << 1) | ((m & 8) >> 1); }
 
 // ---- K-contiguous GEMM:  C[i][j] = epilogue( sum_k A(i,k) W(j,k) ) -------------------------------------------------
 // A: one or two BSP segments along k ([0,Ka) from A, [Ka,K) from A2).  W: a WP16 pack.  C: BSP (planes + exponents,

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void wpack_kernel(WPackTable tb, const float* 
   for (int unit = blockIdx.x; unit < rb32 * nks; unit += gridDim.x) {
     const int ks = unit / rb32, ub = unit - ks * rb32;
     const int r = threadIdx.x >> 3, kp = (threadIdx.x & 7) * 2;       // row inside the unit, first of two k
-    const int ra = ub * 32 + r, ka = ks * 16 + kp;
+    const int ra = ub * 32 + wf16_row(r), ka = ks * 16 + kp;   // slot r of the unit holds matrix row wf16_row(r)
     float x[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
