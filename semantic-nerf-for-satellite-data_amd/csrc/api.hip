@@ -112,6 +112,7 @@ static void plan_bsp(Plan& p) {
   p.o_s2 = planes(p.H); p.e_s2 = etab(p.H); p.o_cs2 = keep_c ? signs(p.H) : 0;
   p.o_s3 = planes(p.H); p.e_s3 = etab(p.H); p.o_cs3 = keep_c ? signs(p.H) : 0;
   p.o_sigo = wtake(Pp * NARROW * 4); p.o_fino = wtake(Pp * NARROW * 4); p.o_suno = wtake(Pp * NARROW * 4);
+  p.o_kcq = wtake((size_t)KCQ_SLOTS * 64);
   p.maxw = p.W > p.FA ? p.W : p.FA;
   if (p.h1w > p.maxw) p.maxw = p.h1w;
   p.nrb = (p.P + 31) / 32;
@@ -834,6 +835,9 @@ int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, c
     g.aux_mode = aux_mode; g.H = ph.as<char>(); g.EH = eh.as<int>(); g.ldh = ldc; g.h_col0 = c_col0; g.Hsign = Hsign;
   }
   g.colsum = colsum; g.ldcs = J;
+  DevBuf ctr; TALLOC(ctr, 64);
+  SNERF_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, st));
+  g.tile_ctr = ctr.as<int>();
   RC(bsp::launch_kc(g, st));
   RC(bsp::launch_from_planes(pc.as<char>(), ec.as<int>(), ldc, c_col0, I, J, C, J, st));
   SNERF_HIP_CHECK(hipStreamSynchronize(st));

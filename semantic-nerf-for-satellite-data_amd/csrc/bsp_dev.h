@@ -16,7 +16,8 @@ __device__ __forceinline__ void dma16(srd_t srd, char* lds_dst, unsigned voff, u
 // where its alias analysis cannot separate the destination from a following LDS read (the dW kernel's transposed reads),
 // puts s_waitcnt vmcnt(0) between them -- every stage request is then drained right after it is issued and the whole
 // DMA latency sits on the critical path of every k-step.  Completion is tracked by the kernels' own counted waits either
-// way.  M0 (the LDS destination) is saved and restored inside.
+// way.  M0 (the LDS destination) is saved and restored inside; s_nop 2 (with the two s_mov in front: five wait states) covers a
+// descriptor / offset operand the compiler has just restored from a spill lane (v_readlane -> vector-memory read).
 typedef unsigned int srd_words __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ srd_words make_srd_words(const void* p, unsigned bytes) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(p);
@@ -25,14 +26,14 @@ __device__ __forceinline__ srd_words make_srd_words(const void* p, unsigned byte
 }
 __device__ __forceinline__ void dma16_asm(srd_words srd, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "s"(lds_byte_addr), "v"(voff), "s"(srd), "s"(soff));
 }
 // one dword per lane (256 B per wave) by the same route
 __device__ __forceinline__ void dma4_asm(srd_words srd, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "s"(lds_byte_addr), "v"(voff), "s"(srd), "s"(soff));
 }
@@ -69,6 +70,23 @@ __device__ __forceinline__ int kc_exp_of_step(const KcArgs& p, int rb, int s, in
   const bool seg2 = s >= nks1;   // branch-free: one load through a selected pointer
   const int* E = seg2 ? p.EA2 : p.EA;
   const int ld = seg2 ? p.lda2 : p.lda, col = seg2 ? p.a2_col0 + 16 * (s - nks1) : p.a_col0 + 16 * s;
+  return E[(size_t)rb * ncb_of(ld) + (col >> 7)];
+}
+
+// The kernel arguments where they lie (kernarg segment, scalar loads).  Every call returns a pointer the compiler must take
+// as new, so values read through it are re-read at the use site instead of being kept in scalar registers (and spilled)
+// across a long loop.  Only for kernels whose single argument is the struct.
+typedef const __attribute__((address_space(4))) KcArgs* kargs_t;
+__device__ __forceinline__ kargs_t kargs() {
+  kargs_t q = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  return q;
+}
+template <class P>
+__device__ __forceinline__ int kc_exp_of_step_p(P p, int rb, int s, int nks1) {
+  const bool seg2 = s >= nks1;
+  const int* E = seg2 ? p->EA2 : p->EA;
+  const int ld = seg2 ? p->lda2 : p->lda, col = seg2 ? p->a2_col0 + 16 * (s - nks1) : p->a_col0 + 16 * s;
   return E[(size_t)rb * ncb_of(ld) + (col >> 7)];
 }
 

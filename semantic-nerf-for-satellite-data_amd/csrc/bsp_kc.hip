@@ -32,13 +32,13 @@ namespace bsp {
 
 constexpr int KC_A = 128 * 128, KC_RING = 3;     // one stage: 128 rows x 32 k (two 16-column groups, 128 B per row)
 constexpr int KC_RINGB = KC_RING * KC_A;         // 48 KiB
-constexpr int KC_STRIPB = 32 * 272;              // one wave's plane strip: 32 points x (256 + 16) B
-constexpr int KC_HREG = 4 * 16384;               // epilogue: two 8 KiB stored-activation regions per wave (overlay the ring)
-constexpr int KC_BIAS = KC_HREG > KC_RINGB ? KC_HREG : KC_RINGB;   // 256 floats: the tile's bias (times w0 / pi for the sine epilogue)
-constexpr int KC_ETAB = KC_BIAS + 1024;          // 128 ints: exponent of every 16-deep k-step
-constexpr int KC_SMAX = KC_ETAB + 512;           // 4 floats: the waves' maxima
-constexpr int KC_HSIGN = KC_SMAX + 64;           // two 256-byte sign-word slots per wave
-constexpr int KC_LDS = KC_HSIGN + 4 * 512;
+constexpr int KC_XREG = KC_RINGB;                // epilogue: 4 KiB per wave (plane strip / second stored-activation buffer)
+constexpr int KC_BIAS = KC_XREG + 4 * 4096;      // 2 x 256 floats: the tile's bias (times w0 / pi for the sine epilogue), by tile parity
+constexpr int KC_ETAB = KC_BIAS + 2 * 1024;      // 2 x 128 ints: exponent of every 16-deep k-step, by tile parity
+constexpr int KC_SMAX = KC_ETAB + 2 * 512;       // 4 floats: the waves' maxima
+constexpr int KC_HSIGN = KC_SMAX + 64;           // four 256-byte sign-word slots per wave
+constexpr int KC_NEXT = KC_HSIGN + 4 * 1024;     // index of the workgroup's next tile (written by wave 0)
+constexpr int KC_LDS = KC_NEXT + 64;
 constexpr float INV_PI = 0.31830988618379067154f;
 constexpr unsigned OOBH = 0x80000000u;           // rejected voffset that survives the addition of an instruction offset
 
@@ -83,114 +83,50 @@ __device__ __forceinline__ float sum32(float v) {
   return v;
 }
 
+// maximum over the wave of non-negative values (DPP inside the 16-lane rows, then the four rows through scalar registers:
+// no lane-index registers to keep alive as ds_bpermute shuffles need)
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 template <int ACT, int AUX, bool COLSUM, bool SIGNS, int SINM>
-__global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
+__global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
+  // The arguments are read from the kernarg segment where they are needed (kargs(): a pointer the compiler must take as
+  // new at every use site, so that it re-reads instead of keeping ~50 scalars alive across the k-loop and spilling them).
+  const kargs_t p = kargs();
   __shared__ __attribute__((aligned(16))) char lds[KC_LDS];
-  float* sbias = reinterpret_cast<float*>(lds + KC_BIAS);
-  int* etab = reinterpret_cast<int*>(lds + KC_ETAB);
   float* smax = reinterpret_cast<float*>(lds + KC_SMAX);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wj0 = wave * 64;
-  int ti, tj;
-  tile_of_block(blockIdx.x, p.tiles_i, p.tiles_j, ti, tj);
-  const int i0 = ti * 128, j0 = tj * 256;
-  const int nks = p.K >> 4, nks1 = p.Ka >> 4;
-  constexpr bool ONEPASS = ACT == ACT_SIN;       // outputs in [-1, 1]: constant block exponent
-
-  // ---- A: per-lane DMA sources.  A stage is 32 k deep = 128 rows x 128 B (two column groups, the tensor's own byte
-  // order); its sixteen 1 KiB pieces (8 rows each) go to the waves round-robin, four per wave, two per 16-deep sub-step.
-  // The 16 B chunk c of a row sits at position c ^ ((row >> 1) & 7): a quarter-wave of ds_read_b128 (eight lanes, eight
-  // consecutive rows, one chunk) then covers four distinct positions twice -> all 32 banks in two passes, no conflict.
+  const int tiles_i = p->tiles_i, tiles_j = p->tiles_j, ntiles = tiles_i * tiles_j;
+  const int nks = p->K >> 4, nks1 = p->Ka >> 4;
   const int nst = (nks + 1) >> 1, nst1 = nks1 >> 1;          // stages; stages of the first segment (Ka % 32 == 0 if two)
-  const srd_t srdA = make_srd(p.A + ((size_t)i0 * p.lda + p.a_col0) * 4,
-                              clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda + p.Ka) * 4ull : 0ull));
-  const srd_t srdA2 = make_srd(p.A2 + ((size_t)i0 * p.lda2 + p.a2_col0) * 4,
-                               clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda2 + (p.K - p.Ka)) * 4ull : 0ull));
-  unsigned voA[4], voA2[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = 8 * (wave + 4 * q) + (lane >> 3);
-    const unsigned c = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
-    const bool in = i0 + row < p.I;
-    voA[q] = in ? (unsigned)row * (unsigned)p.lda * 4u + 16u * c : OOB;
-    voA2[q] = in ? (unsigned)row * (unsigned)p.lda2 * 4u + 16u * c : OOB;
-  }
+  constexpr bool ONEPASS = ACT == ACT_SIN;                   // outputs in [-1, 1]: constant block exponent
+  constexpr bool BIAS = AUX == AUX_NONE && !COLSUM;           // forward launches; the backward ones (column sums) have none
+
+  // ---- per-lane constants (the same for every tile of this workgroup) --------------------------------------------------
+  // A: a stage is 32 k deep = 128 rows x 128 B (two column groups, the tensor's own byte order); its sixteen 1 KiB pieces
+  // (8 rows each) go to the waves round-robin, four per wave, two per 16-deep sub-step.  The 16 B chunk c of a row sits at
+  // position c ^ ((row >> 1) & 7): a quarter-wave of ds_read_b128 (eight lanes, eight consecutive rows, one chunk) then
+  // covers four distinct positions twice -> all 32 banks in two passes, no conflict.  Rows beyond I are rejected by the
+  // descriptor (its extent ends with row I - 1).
+  auto a_lane_off = [&](int q, int ld, int l) -> unsigned {       // piece q of this wave: row, swizzled chunk
+    const int row = 8 * (wave + 4 * q) + (l >> 3);
+    return (unsigned)row * (unsigned)ld * 4u + 16u * (unsigned)((l & 7) ^ ((row >> 1) & 7));
+  };
+  // Lane-derived values that only a tile's prologue / epilogue needs are recomputed there from an opaque copy of the lane
+  // index: derived from `lane` itself they are loop-invariant, get hoisted out of the tile loop and then occupy registers
+  // all through the k-loop.
+  auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
   char* const dst0 = lds + wave * 1024;
-  // The descriptor, the lanes' offsets and the stage bias of the segment being requested are loop-carried and replaced
-  // ONCE, at the stage where the second segment starts (selecting them per request cost ~16 scalar instructions per
-  // piece, more than an MFMA gap hides); a stage beyond K is rejected through the scalar offset.
-  srd_t srdCur = srdA;
-  unsigned voCur[4] = {voA[0], voA[1], voA[2], voA[3]};
-  int sbias_st = 0;
-  const int seg_switch = p.Ka < p.K ? nst1 : 0x7fffffff;
-  auto enter_stage = [&](int S) {     // before the first piece of stage S
-    if (__builtin_expect(S == seg_switch, 0)) {
-      srdCur = srdA2; sbias_st = nst1;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) voCur[q] = voA2[q];
-    }
-  };
-  auto issueA = [&](int S, int slot, int q) {
-    dma16(srdCur, dst0 + slot * KC_A + 4096 * q, voCur[q], S < nst ? (unsigned)(S - sbias_st) * 128u : OOB);
-  };
-  // ---- W: fragment-ordered pack; unit (ks, rb32) = 2 KiB = [plane][lane][16 B]; this wave reads units rb32 = u0, u0 + 1
-  const srd_words srdW = make_srd_words(p.W, p.w_bytes);
-  const unsigned w_u0 = (unsigned)((p.w_row0 + j0 + wj0) >> 5), w_ks0 = (unsigned)(p.w_k0 >> 4);
-  const unsigned voW = 16u * (unsigned)lane;
-  struct BFrag { u32x4 h[2], l[2]; };
-  // The weight loads are asm statements with their completion counted by hand (wait_b below).  As builtins, hipcc's own
-  // vm-counter bookkeeping put conservative waits behind them at the loop header (the two-step prefetch was undone) and
-  // re-used the registers of the fragment set that is dead at the header as VALU temporaries, each with a WAW wait on a
-  // load.  A step beyond K is rejected through the scalar offset.
-  auto loadB2 = [&](int s, BFrag& b, int half) {     // two of the four weight loads of sub-step s
-    const unsigned so = s < nks ? ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_u0) * 2048u : OOB;
-    if (half == 0) {
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(b.h[0]) : "v"(voW), "s"(srdW), "s"(so));
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024" : "=v"(b.l[0]) : "v"(voW), "s"(srdW), "s"(so));
-    } else {
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:2048" : "=v"(b.h[1]) : "v"(voW), "s"(srdW), "s"(so));
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:3072" : "=v"(b.l[1]) : "v"(voW), "s"(srdW), "s"(so));
-    }
-  };
-  // everything but the six youngest requests (= the previous sub-step's) has landed; names the fragments so that no use of
-  // them can be scheduled above the wait
-  auto wait_b = [&](BFrag& b) {
-    asm volatile("s_waitcnt vmcnt(6)" : "+v"(b.h[0]), "+v"(b.l[0]), "+v"(b.h[1]), "+v"(b.l[1])::"memory");
-  };
-
-  // ---- exponents along k: table in LDS + a bit per step where the scale changes (128 steps at most: K <= 2048).
-  const int ti_e = min(ti, (p.I + 127) / 128 - 1);
-  const int sA = lane, sB = lane + 64;
-  const int eA = sA < nks ? kc_exp_of_step(p, ti_e, sA, nks1) : 0;
-  const int eB = sB < nks ? kc_exp_of_step(p, ti_e, sB, nks1) : 0;
-  const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti_e, sA - 1, nks1) : eA;
-  const int eBp = sB < nks ? kc_exp_of_step(p, ti_e, sB - 1, nks1) : eB;
-  const int e_last = kc_exp_of_step(p, ti_e, nks - 1, nks1);
-  float bias_t = 0.f;                              // the tile's bias, one column per thread
-  if (AUX == AUX_NONE && p.bias != nullptr && j0 + t < p.J) bias_t = p.bias[j0 + t];
-  // Both operands are requested ahead: W two sub-steps, A two stages.  vm-counter order: [W(0) A(0) x 4] [W(1) A(1) x 4],
-  // then per sub-step s = 2 S + u: [W(s + 2) x 4] [two pieces of A(S + 2)] -- at the top of sub-step s the six requests
-  // of sub-step s - 1 may be outstanding and everything older has landed, which covers W(s) and all of stage S (issued
-  // during stage S - 2): s_waitcnt vmcnt(6).
-  BFrag bq0, bq1, bq2;
-  loadB2(0, bq0, 0); loadB2(0, bq0, 1);
-  issueA(0, 0, 0); issueA(0, 0, 1); issueA(0, 0, 2); issueA(0, 0, 3);
-  loadB2(1, bq1, 0); loadB2(1, bq1, 1);
-  enter_stage(1);
-  issueA(1, 1, 0); issueA(1, 1, 1); issueA(1, 1, 2); issueA(1, 1, 3);
-  if (wave == 0) { etab[sA] = eA; etab[sB] = eB; }
-  if (AUX == AUX_NONE) sbias[t] = bias_t * (ACT == ACT_SIN ? p.w0 * INV_PI : 1.f);
-  const unsigned long long chg0 = __builtin_amdgcn_ballot_w64(eA != eAp), chg1 = __builtin_amdgcn_ballot_w64(eB != eBp);
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
-
   // A fragment addresses: lane -> (row l & 31, k half l >> 5); chunk (4 u + 2 pl + half) of sub-step u sits at position
   // chunk ^ ((row >> 1) & 7)
   const int rowl = lane & 31, kh = lane >> 5, swz = (rowl >> 1) & 7;
@@ -199,291 +135,459 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs p) {
   for (int u = 0; u < 2; ++u)
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) fo[u][pl] = (unsigned)rowl * 128u + (unsigned)(((4 * u + 2 * pl + kh) ^ swz) << 4);
+  // W: fragment-ordered pack; unit (ks, rb32) = 2 KiB = [plane][lane][16 B]; a wave reads units rb32 = u0, u0 + 1
+  const srd_words srdW = make_srd_words(p->W, p->w_bytes);
+  const unsigned w_ks0 = (unsigned)(p->w_k0 >> 4), w_rb32 = (unsigned)p->w_rb32;
+  const bool two_seg = p->Ka < p->K;
+  const unsigned voW = 16u * (unsigned)lane;
 
-  // One 16-deep sub-step s = 2 S + u of stage S: 24 MFMAs on the fragments `fa` (read from LDS during the PREVIOUS sub-step)
-  // and the weight registers `bc`; `bn` receives the weight fragments of sub-step s + 2.  A single wave issues one
-  // instruction per ~4 cycles, an MFMA occupies the matrix pipe for 32: whatever is issued in a block of its own leaves the
-  // pipe idle, so every non-MFMA instruction sits in a gap between MFMAs: per 32-point block mi the six MFMAs run hi*lo,
-  // lo*hi, hi*hi on two accumulators each, the lo fragment of mi is re-read for sub-step s + 1 as soon as its last MFMA has
-  // been issued, the hi fragment after the block, and the four weight loads / two DMA pieces are spread over the blocks.
-  // The workgroup barrier of a new stage comes in the middle of the last sub-step of its predecessor (before the first
-  // read of the new stage): every wave has passed the top-of-sub-step wait that covers its own pieces of stage S + 1
-  // (issued during stage S - 1) and has finished reading stage S - 1, whose slot the requests of stage S + 2 (issued after
-  // that point in program order) overwrite.
-  struct AFrag { f16x8 h[4], l[4]; };
-  AFrag fa;
-  auto step = [&](int s, int slot, int u, BFrag& bc, BFrag& bn) {
-    wait_b(bc);
-    if (__builtin_expect((((s & 64) ? chg1 : chg0) >> (s & 63)) & 1ull, 0)) {
-      const int de = etab[s] - etab[s - 1];
+  // ---- state of the tile whose operands are being requested ------------------------------------------------------------
+  int ti = 0, tj = 0, i0 = 0, j0 = 0, e_last = 0;
+  unsigned w_u0 = 0;
+  int eA = 0, eB = 0;              // exponent of k-step (lane) / (lane + 64)
+  float bias_t = 0.f;              // the tile's bias, one column per thread
+  // The descriptor, the lanes' offsets and the stage bias of the segment being requested are loop-carried and replaced
+  // ONCE, at the stage where the second segment starts (selecting them per request cost ~16 scalar instructions per
+  // piece, more than an MFMA gap hides); a stage beyond K is rejected through the scalar offset.
+  srd_t srdCur;
+  unsigned voCur[4];
+  int sbias_st = 0;
+  const int seg_switch = two_seg ? nst1 : 0x7fffffff;
+  auto prepare = [&](int vb) {
+    const kargs_t a = kargs();
+    const int l = opaque(lane);
+    tile_of_block(vb, tiles_i, tiles_j, ti, tj);
+    i0 = ti * 128; j0 = tj * 256;
+    const int lda = a->lda;
+    srdCur = make_srd(a->A + ((size_t)i0 * lda + a->a_col0) * 4, clamp_bytes(((unsigned long long)(a->I - i0 - 1) * lda + a->Ka) * 4ull));
+    sbias_st = 0;
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+    for (int q = 0; q < 4; ++q) voCur[q] = a_lane_off(q, lda, l);
+    w_u0 = (unsigned)((a->w_row0 + j0 + wj0) >> 5);
+    // exponents of the k-steps (lane) and (lane + 64) and of the last one: the fields of both segments as scalars, the choice per lane
+    const int* EA1 = a->EA; const int* EA2 = a->EA2;
+    const int ncb1 = ncb_of(lda), ncb2 = ncb_of(a->lda2), ac1 = a->a_col0, ac2 = a->a2_col0;
+    auto exp_of = [&](int s) {
+      const bool seg2 = s >= nks1;
+      const int* E = seg2 ? EA2 : EA1;
+      const int col = seg2 ? ac2 + 16 * (s - nks1) : ac1 + 16 * s;
+      return E[(size_t)ti * (seg2 ? ncb2 : ncb1) + (col >> 7)];
+    };
+    eA = l < nks ? exp_of(l) : 0;
+    eB = l + 64 < nks ? exp_of(l + 64) : 0;
+    e_last = exp_of(nks - 1);
+    if (BIAS) { const int tt = opaque(t); bias_t = (a->bias != nullptr && j0 + tt < a->J) ? a->bias[j0 + tt] : 0.f; }
+  };
+  auto enter_stage = [&](int S) {     // before the first piece of stage S
+    if (__builtin_expect(S == seg_switch, 0)) {
+      const kargs_t a = kargs();
+      srdCur = make_srd(a->A2 + ((size_t)i0 * a->lda2 + a->a2_col0) * 4, clamp_bytes(((unsigned long long)(a->I - i0 - 1) * a->lda2 + (a->K - a->Ka)) * 4ull));
+      sbias_st = nst1;
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
-    }
-    const char* sn = lds + (u ? (slot + 1) % KC_RING : slot) * KC_A;   // where sub-step s + 1 reads
-    const f16x8 bh0 = __builtin_bit_cast(f16x8, bc.h[0]), bh1 = __builtin_bit_cast(f16x8, bc.h[1]);
-    const f16x8 bl0 = __builtin_bit_cast(f16x8, bc.l[0]), bl1 = __builtin_bit_cast(f16x8, bc.l[1]);
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, fa.h[mi], acc[mi][0], 0, 0, 0);
-      acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, fa.h[mi], acc[mi][1], 0, 0, 0);
-      if (mi < 2) loadB2(s + 2, bn, mi);
-      if (mi == 2 && u == 0) enter_stage((s >> 1) + 2);
-      if (mi >= 2) issueA((s >> 1) + 2, (slot + 2) % KC_RING, 2 * u + (mi - 2));   // two of the four pieces of stage S + 2
-      acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.l[mi], acc[mi][0], 0, 0, 0);
-      acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.l[mi], acc[mi][1], 0, 0, 0);
-      if (mi == 0 && u == 1) { __builtin_amdgcn_sched_barrier(0); barrier_raw(); __builtin_amdgcn_sched_barrier(0); }
-      const f16x8 nl = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
-      acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.h[mi], acc[mi][0], 0, 0, 0);
-      acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.h[mi], acc[mi][1], 0, 0, 0);
-      fa.l[mi] = nl;
-      fa.h[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);
-      __builtin_amdgcn_sched_barrier(0);   // keep the blocks apart: left alone, the scheduler gathers the reads at the end
+      for (int q = 0; q < 4; ++q) voCur[q] = a_lane_off(q, a->lda2, opaque(lane));
     }
   };
-  // fragments of sub-step 0: stage 0 (and W(0)) are home when all but the eight youngest requests (W(1), stage 1) are
-  wait_vm<8>();
-  barrier_raw();
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) { fa.h[mi] = ldsfrag(lds + 4096 * mi + fo[0][0]); fa.l[mi] = ldsfrag(lds + 4096 * mi + fo[0][1]); }
-  // The k-loop runs at raised priority: while the SIMD's other wave (the co-resident workgroup) is in its VALU-heavy
-  // epilogue, MFMA issue goes first and the epilogue stream fills the 24 of every 32 cycles the matrix pipe leaves free.
-  __builtin_amdgcn_s_setprio(2);
-  for (int s = 0; s < 2 * nst; s += 6) {   // an odd count of 16-deep steps runs one sub-step on zero weights
-    step(s, 0, 0, bq0, bq2);
-    step(s + 1, 0, 1, bq1, bq0);
-    if (s + 2 < 2 * nst) { step(s + 2, 1, 0, bq2, bq1); step(s + 3, 1, 1, bq0, bq2); }
-    if (s + 4 < 2 * nst) { step(s + 4, 2, 0, bq1, bq0); step(s + 5, 2, 1, bq2, bq1); }
-  }
-  __builtin_amdgcn_s_setprio(0);
+  auto issueA = [&](int S, int slot, int q) {
+    dma16(srdCur, dst0 + slot * KC_A + 4096 * q, voCur[q], S < nst ? (unsigned)(S - sbias_st) * 128u : OOB);
+  };
+  auto headA = [&]() {                // stages 0 and 1 of the prepared tile
+    enter_stage(0);
+    issueA(0, 0, 0); issueA(0, 0, 1); issueA(0, 0, 2); issueA(0, 0, 3);
+    enter_stage(1);
+    issueA(1, 1, 0); issueA(1, 1, 1); issueA(1, 1, 2); issueA(1, 1, 3);
+  };
+  struct BFrag { u32x4 h[2], l[2]; };
+  // The weight loads are asm statements with their completion counted by hand.  As builtins, hipcc's own vm-counter
+  // bookkeeping put conservative waits behind them at the loop header (the two-step prefetch was undone) and re-used the
+  // registers of the fragment set that is dead at the header as VALU temporaries, each with a WAW wait on a load.  A step
+  // beyond K is rejected through the scalar offset.
+  auto loadB2 = [&](int s, BFrag& b, int half) {     // two of the four weight loads of sub-step s
+    const unsigned so = s < nks ? ((w_ks0 + (unsigned)s) * w_rb32 + w_u0) * 2048u : OOB;
+    // (s_nop 4: a scalar operand the compiler has just restored from a spill lane (v_readlane) needs five wait states before
+    //  a vector-memory instruction reads it, and nothing inside an asm statement is padded for us)
+    if (half == 0)
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024"
+                   : "=&v"(b.h[0]), "=&v"(b.l[0]) : "v"(voW), "s"(srdW), "s"(so));
+    else
+      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen offset:2048\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:3072"
+                   : "=&v"(b.h[1]), "=&v"(b.l[1]) : "v"(voW), "s"(srdW), "s"(so));
+  };
+  // everything but the six youngest requests (= the previous sub-step's) has landed; names the fragments so that no use of
+  // them can be scheduled above the wait
+  auto wait_b = [&](BFrag& b) {
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(b.h[0]), "+v"(b.l[0]), "+v"(b.h[1]), "+v"(b.l[1])::"memory");
+  };
+  auto pin_b = [&](BFrag& b) { asm volatile("" : "+v"(b.h[0]), "+v"(b.l[0]), "+v"(b.h[1]), "+v"(b.l[1])::"memory"); };
+  BFrag bq0, bq1, bq2;
+  auto headW = [&]() { loadB2(0, bq0, 0); loadB2(0, bq0, 1); loadB2(1, bq1, 0); loadB2(1, bq1, 1); };
 
-  // ---- epilogue.  Lane l: point pt = l & 31 of each 32-point block mi; register r of block (mi, nj) is column
-  //      64 wave + 32 nj + 16 (r >> 3) + 8 (l >> 5) + (r & 7) of the tile.  The ring is dead from here on: its LDS holds the
-  //      waves' plane strips (results on their way out) and, for the derivative epilogues, the stored activations on their
-  //      way in.
-  wait_vm<0>();        // rejected requests behind the last stage write zeros into the ring: drain before re-using it
-  barrier_raw();
-  const int e_in = e_last + *p.EW;          // acc = true value * 2^e_in
-  const bool e_small = e_in >= -120 && e_in <= 120;
-  if (!e_small) {   // exponents beyond a single fp32 factor (never with sane data): scale the accumulators first
+  // ---- the workgroup walks its tiles; the operands of tile n + 1 (stages 0, 1 of A into ring slots 0, 1; the weight
+  //      fragments of sub-steps 0, 1) are requested during the epilogue of tile n ----------------------------------------------
+  // Tiles: the first one by block index, the following ones drawn from a counter per XCD group (blocks b and b + 8 share
+  // an XCD under round-robin placement; the tile map keeps the tiles of one group contiguous, tile_of_block).  The
+  // workgroups of a CU do not run at the same pace (co-residency, clocks): a fixed share per workgroup ends with the
+  // slowest one working alone (measured 671 k cycles against a median of 575 k for 8 tiles each).
+  int* const tile_ctr = p->tile_ctr;
+  const bool dyn = tile_ctr != nullptr;
+  const int n_grp = (gridDim.x & 7) == 0 ? 8 : 1, grp = (int)blockIdx.x & (n_grp - 1);
+  const unsigned ctr_off = 4u * (unsigned)grp;
+  int vb = blockIdx.x;
+  prepare(vb);
+  headW();
+  headA();
+  bool first = true;
+  for (int it = 0;; ++it) {
+    float* sbias = reinterpret_cast<float*>(lds + KC_BIAS + (it & 1) * 1024);
+    int* etab = reinterpret_cast<int*>(lds + KC_ETAB + (it & 1) * 512);
+    // exponents along k: table in LDS + a bit per step where the scale changes (128 steps at most: K <= 2048)
+    int eAp = __builtin_amdgcn_update_dpp(eA, eA, 0x138, 0xF, 0xF, false);       // wave_shr 1: the previous step's exponent
+    int eBp = __builtin_amdgcn_update_dpp(eB, eB, 0x138, 0xF, 0xF, false);
+    const int eA63 = __builtin_amdgcn_readlane(eA, 63);
+    if (opaque(lane) == 0) eBp = eA63;
+    if (lane + 64 >= nks) eBp = eB;
+    if (lane >= nks) eAp = eA;
+    if (wave == 0) { etab[lane] = eA; etab[lane + 64] = eB; }
+    if (BIAS) sbias[t] = bias_t * (ACT == ACT_SIN ? kargs()->w0 * INV_PI : 1.f);
+    const unsigned long long chg0 = __builtin_amdgcn_ballot_w64(eA != eAp), chg1 = __builtin_amdgcn_ballot_w64(eB != eBp);
+
+    f32x16 acc[4][2];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], -e_in);
-  }
-  const float inv_in = e_small ? pow2f(-e_in) : 1.f;
-  const int pt = lane & 31, lh = lane >> 5;
-  const int nrows = min(128, p.I - i0);                        // > 0: the grid covers ceil(I / 128) row tiles
-  const int jw = j0 + wj0;                                     // first column of the wave
-  const bool wave_cols = jw < p.J;
-  const size_t offC = uniform_sz(((size_t)i0 * p.ldc + p.c_col0) * 4);
-  const srd_t srdC = make_srd(p.C + offC, clamp_bytes(((unsigned long long)(nrows - 1) * p.ldc + p.J) * 4ull));
-  // Plane strip of one 32-point block: [32 points][272 B] = the wave's 64 columns as they lie in memory (four 64-byte
-  // groups [hi | lo]) + 16 B of padding.  A lane writes its 16-byte pieces (eight consecutive lanes: 8 points x 16 B at a
-  // 272-byte pitch = all 32 banks), then the wave reads the strip back four whole rows per instruction and stores 4 x 256
-  // contiguous bytes.
-  char* const strip = lds + wave * KC_STRIPB;
-  const unsigned sw_off = (unsigned)pt * 272u + 16u * (unsigned)lh;                       // + 64 gq (+ 32: lo plane)
-  const int srow = lane >> 4, schunk = lane & 15;
-  const unsigned sr_off = (unsigned)srow * 272u + 16u * (unsigned)schunk;                 // + 4 * 272 per pass
-  const bool chunk_ok = jw + 16 * (schunk >> 2) < p.J;                                    // J % 16 == 0
-  const unsigned voC = chunk_ok ? (unsigned)srow * (unsigned)p.ldc * 4u + (unsigned)(jw >> 4) * 64u + 16u * (unsigned)schunk : OOBH;
-  const unsigned stepC4 = 4u * (unsigned)p.ldc * 4u;
-  auto strip_put = [&](int gq, const u32x4& hi, const u32x4& lo) {
-    *reinterpret_cast<u32x4*>(strip + sw_off + 64 * gq) = hi;
-    *reinterpret_cast<u32x4*>(strip + sw_off + 64 * gq + 32) = lo;
-  };
-  auto strip_flush = [&](int mi) {     // rows beyond I are rejected by the descriptor
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const u32x4 d = *reinterpret_cast<const u32x4*>(strip + sr_off + 4 * 272 * ps);
-      __builtin_amdgcn_raw_buffer_store_b128(d, srdC, voC + (unsigned)(8 * mi + ps) * stepC4, 0, 0);
-    }
-  };
-  float bj[4][8];
-  if (AUX == AUX_NONE) {
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const float4 b0 = *reinterpret_cast<const float4*>(&sbias[wj0 + 16 * gq + 8 * lh]);
-      const float4 b1 = *reinterpret_cast<const float4*>(&sbias[wj0 + 16 * gq + 8 * lh + 4]);
-      bj[gq][0] = b0.x; bj[gq][1] = b0.y; bj[gq][2] = b0.z; bj[gq][3] = b0.w;
-      bj[gq][4] = b1.x; bj[gq][5] = b1.y; bj[gq][6] = b1.z; bj[gq][7] = b1.w;
-    }
-  }
-
-  if constexpr (ONEPASS) {
-    // ---- sine: one pass.  u = acc * (2^-e w0 / pi) + b w0 / pi (bias row staged in LDS, already scaled)
-    const float su = inv_in * p.w0 * INV_PI;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      unsigned sw = 0u;
-#pragma unroll
       for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-          const int gq = 2 * nj + gg;
-          float v[8];
+        for (int r = 0; r < 16; ++r) acc[mi][nj][r] = 0.f;
+
+    // One 16-deep sub-step s = 2 S + u of stage S: 24 MFMAs on the fragments `fa` (read from LDS during the PREVIOUS sub-step)
+    // and the weight registers `bc`; `bn` receives the weight fragments of sub-step s + 2.  A single wave issues one
+    // instruction per ~4 cycles, an MFMA occupies the matrix pipe for 32: whatever is issued in a block of its own leaves
+    // the pipe idle, so every non-MFMA instruction sits in a gap between MFMAs: per 32-point block mi the six MFMAs run
+    // hi*lo, lo*hi, hi*hi on two accumulators each, the lo fragment of mi is re-read for sub-step s + 1 as soon as its last
+    // MFMA has been issued, the hi fragment after the block, and the four weight loads / two DMA pieces are spread over the
+    // blocks.  The workgroup barrier of a new stage comes in the middle of the last sub-step of its predecessor (before the
+    // first read of the new stage): every wave has passed the top-of-sub-step wait that covers its own pieces of stage S + 1
+    // (issued during stage S - 1) and has finished reading stage S - 1, whose slot the requests of stage S + 2 (issued
+    // after that point in program order) overwrite.
+    // vm-counter order inside a tile: per sub-step s = 2 S + u: [W(s + 2) x 4] [two pieces of A(S + 2)] -- at the top of
+    // sub-step s >= 2 the six requests of sub-step s - 1 may be outstanding and everything older has landed, which covers
+    // W(s) and all of stage S: s_waitcnt vmcnt(6).  Sub-steps 0 and 1 run on what the tile-start wait below has retired.
+    struct AFrag { f16x8 h[4], l[4]; };
+    AFrag fa;
+    auto step = [&](int s, int slot, int u, BFrag& bc, BFrag& bn) {
+      if (s >= 2) wait_b(bc);
+      if (__builtin_expect((((s & 64) ? chg1 : chg0) >> (s & 63)) & 1ull, 0)) {
+        const int de = etab[s] - etab[s - 1];
 #pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = fmaf(acc[mi][nj][8 * gg + c], su, bj[gq][c]);
-          sinpi8<SIGNS, SINM>(v, sw);
-          u32x4 hi, lo;
-          split8(v, 8192.f, hi, lo);
-          strip_put(gq, hi, lo);
-        }
-      if (SIGNS && p.Csign != nullptr && wave_cols && 32 * mi < nrows)
-        p.Csign[((size_t)((i0 >> 5) + mi) * ((p.ldc + 63) >> 6) + ((p.c_col0 + jw) >> 6)) * 64 + lane] = sw;
-      strip_flush(mi);
-    }
-    if ((wave & 1) == 0 && lane == 0 && wave_cols) p.EC[(size_t)ti * ncb_of(p.ldc) + ((p.c_col0 + jw) >> 7)] = 13;
-  } else {
-    // ---- two passes.  Pass A: final values in place of the accumulators, their |max|, column sums.
-    float wmax = 0.f;
-    float cs[2][16];
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) cs[nj][r] = 0.f;
-    int eH = 0;
-    if (AUX != AUX_NONE && wave_cols) eH = p.EH[(size_t)ti_e * ncb_of(p.ldh) + ((p.h_col0 + jw) >> 7)];
-    const float inv_h = pow2f(-eH);
-    // Stored activations (derivative epilogues): block mi of the wave = 32 points x 256 B, fetched by LDS-DMA in eight 1 KiB
-    // pieces (4 whole rows each) into one of two 8 KiB regions of the wave, block mi + 1 while block mi is worked on.  Chunk
-    // c of point row q lies at position c ^ (q & 15) (swizzle on the source address): the lanes of a ds_read_b128 group
-    // hold 16 different points -> 16 different positions.  The sign words (one dword per lane and block) come the same way.
-    const size_t offH = uniform_sz(AUX != AUX_NONE ? ((size_t)i0 * p.ldh + p.h_col0) * 4 : 0);
-    const srd_words srdH = make_srd_words(AUX != AUX_NONE ? p.H + offH : nullptr,
-                                          AUX != AUX_NONE ? clamp_bytes(((unsigned long long)(nrows - 1) * p.ldh + p.J) * 4ull) : 0u);
-    const srd_words srdS = make_srd_words(AUX == AUX_SINREC ? p.Hsign : nullptr,
-                                          AUX == AUX_SINREC ? clamp_bytes(sign_words((size_t)p.I, p.ldh) * 4ull) : 0u);
-    const unsigned hreg0 = __builtin_amdgcn_readfirstlane(lds_addr(lds + wave * 16384));
-    const unsigned sreg0 = __builtin_amdgcn_readfirstlane(lds_addr(lds + KC_HSIGN + wave * 512));
-    auto dma_h = [&](int mi) {
-      if (AUX == AUX_NONE) return;
-#pragma unroll
-      for (int pc = 0; pc < 8; ++pc) {
-        const int q = 4 * pc + (lane >> 4);                       // point row inside the block
-        const int c = (lane & 15) ^ (q & 15);                     // global chunk this lane fetches
-        const bool ok = jw + 16 * (c >> 2) < p.J;
-        const unsigned vo = ok ? (unsigned)(32 * mi + q) * (unsigned)p.ldh * 4u + (unsigned)(jw >> 4) * 64u + 16u * (unsigned)c : OOBH;
-        dma16_asm(srdH, hreg0 + (unsigned)((mi & 1) * 8192 + pc * 1024), vo, 0u);
+          for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], de);
       }
-      if (AUX == AUX_SINREC) {
-        const bool ok = wave_cols && 32 * mi < nrows;
-        const unsigned vo = ok ? (unsigned)((((size_t)((i0 >> 5) + mi) * ((p.ldh + 63) >> 6) + ((p.h_col0 + jw) >> 6)) * 64 + lane) * 4) : OOBH;
-        dma4_asm(srdS, sreg0 + (unsigned)((mi & 1) * 256), vo, 0u);
+      const char* sn = lds + (u ? (slot + 1) % KC_RING : slot) * KC_A;   // where sub-step s + 1 reads
+      const f16x8 bh0 = __builtin_bit_cast(f16x8, bc.h[0]), bh1 = __builtin_bit_cast(f16x8, bc.h[1]);
+      const f16x8 bl0 = __builtin_bit_cast(f16x8, bc.l[0]), bl1 = __builtin_bit_cast(f16x8, bc.l[1]);
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, fa.h[mi], acc[mi][0], 0, 0, 0);
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, fa.h[mi], acc[mi][1], 0, 0, 0);
+        if (mi < 2) loadB2(s + 2, bn, mi);
+        if (mi == 2 && u == 0) enter_stage((s >> 1) + 2);
+        if (mi >= 2) issueA((s >> 1) + 2, (slot + 2) % KC_RING, 2 * u + (mi - 2));   // two of the four pieces of stage S + 2
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.l[mi], acc[mi][0], 0, 0, 0);
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.l[mi], acc[mi][1], 0, 0, 0);
+        if (mi == 0 && u == 1) { __builtin_amdgcn_sched_barrier(0); barrier_raw(); __builtin_amdgcn_sched_barrier(0); }
+        const f16x8 nl = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
+        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.h[mi], acc[mi][0], 0, 0, 0);
+        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.h[mi], acc[mi][1], 0, 0, 0);
+        fa.l[mi] = nl;
+        fa.h[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the blocks apart: left alone, the scheduler gathers the reads at the end
       }
     };
-    constexpr int NDMA = AUX == AUX_SINREC ? 9 : 8;               // requests per block
-    dma_h(0);
-    dma_h(1);
-    // derivative epilogues: the accumulator's scale and |w0| in one factor; the sign bits are xor-ed with w0's own sign
-    const unsigned w0mag = __float_as_uint(fabsf(p.w0) * inv_in);
-    const unsigned sflip = p.w0 < 0.f ? 0xFFFFFFFFu : 0u;
+    // Tile start: W(0), W(1) and this wave's pieces of stages 0 AND 1 are home (sub-steps 0 and 1 have no wait of their own,
+    // and the barrier inside sub-step 1 publishes stage 1).  First tile: they are the only requests.  Later tiles: they were
+    // requested during the previous epilogue, which has issued at least 32 stores since.  The barrier also ends every wave's
+    // use of the epilogue's LDS regions before the requests of stage 2 go out.
+    if (first) wait_vm<0>(); else wait_vm<32>();
+    pin_b(bq0); pin_b(bq1);
+    barrier_raw();
+    // The tile after this one: drawn from the counter of the workgroup's XCD group while this tile's k-loop runs (a returning
+    // atomic of ONE lane; it is this wave's oldest request by the time sub-step 2 waits, and read after the loop's drain).
+    int drawn = 0;
+    if (dyn && wave == 0 && opaque(lane) == 0)
+      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(drawn) : "v"(ctr_off), "v"(1), "s"(tile_ctr) : "memory");
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      if (AUX != AUX_NONE) {
-        if (mi < 3) wait_vm<NDMA>(); else wait_vm<0>();           // block mi is home (block mi + 1 may be in flight)
+    for (int mi = 0; mi < 4; ++mi) { fa.h[mi] = ldsfrag(lds + 4096 * mi + fo[0][0]); fa.l[mi] = ldsfrag(lds + 4096 * mi + fo[0][1]); }
+    // The k-loop runs at raised priority: while the SIMD's other wave (the co-resident workgroup) is in its VALU-heavy
+    // epilogue, MFMA issue goes first and the epilogue stream fills the 24 of every 32 cycles the matrix pipe leaves free.
+    __builtin_amdgcn_s_setprio(2);
+    for (int s = 0; s < 2 * nst; s += 6) {   // an odd count of 16-deep steps runs one sub-step on zero weights
+      step(s, 0, 0, bq0, bq2);
+      step(s + 1, 0, 1, bq1, bq0);
+      if (s + 2 < 2 * nst) { step(s + 2, 1, 0, bq2, bq1); step(s + 3, 1, 1, bq0, bq2); }
+      if (s + 4 < 2 * nst) { step(s + 4, 2, 0, bq1, bq0); step(s + 5, 2, 1, bq2, bq1); }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    wait_vm<0>();        // rejected requests behind the last stage write zeros into the ring: drain before re-using it
+    if (dyn && wave == 0 && opaque(lane) == 0) {
+      asm volatile("" : "+v"(drawn));
+      *reinterpret_cast<volatile int*>(lds + KC_NEXT) = (int)gridDim.x + n_grp * drawn + grp;
+    }
+    barrier_raw();
+
+    // ---- this tile's coordinates for the epilogue; then the next tile's operands are requested ----------------------------
+    const int c_ti = ti, c_i0 = i0, c_j0 = j0, c_elast = e_last;
+    const int vbn = dyn ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(lds + KC_NEXT)) : vb + (int)gridDim.x;
+    const bool more = vbn < ntiles;
+    if (more) {
+      prepare(vbn);
+      if (ONEPASS) headW();
+      headA();
+    }
+
+    // ---- epilogue.  Lane l: point pt = l & 31 of each 32-point block mi; register r of block (mi, nj) is column
+    //      64 wave + 32 nj + 16 (r >> 3) + 8 (l >> 5) + (r & 7) of the tile.  Ring slots 0 and 1 are being refilled; slot 2
+    //      and the region behind the ring hold the waves' plane strips (results on their way out) and, for the derivative
+    //      epilogues, the stored activations on their way in.
+    const kargs_t e = kargs();
+    const int e_in = c_elast + *e->EW;          // acc = true value * 2^e_in
+    const bool e_small = e_in >= -120 && e_in <= 120;
+    if (!e_small) {   // exponents beyond a single fp32 factor (never with sane data): scale the accumulators first
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], -e_in);
+    }
+    const float inv_in = e_small ? pow2f(-e_in) : 1.f;
+    const int el = opaque(lane);               // see `opaque` above
+    const int pt = el & 31, lh = el >> 5;
+    const int nrows = min(128, e->I - c_i0);                      // > 0: the grid covers ceil(I / 128) row tiles
+    const int jw = c_j0 + wj0;                                   // first column of the wave
+    const bool wave_cols = jw < e->J;
+    const size_t offC = uniform_sz(((size_t)c_i0 * e->ldc + e->c_col0) * 4);
+    const srd_t srdC = make_srd(e->C + offC, clamp_bytes(((unsigned long long)(nrows - 1) * e->ldc + e->J) * 4ull));
+    // Plane strip of one (32-point block, 32-column half) = [32 points][128 B]: the two 64-byte groups [hi | lo] of the
+    // half as they lie in memory, chunk c at position c ^ (point & 7).  A el writes its 16-byte pieces (eight consecutive
+    // lanes: eight positions = all 32 banks), then the wave reads the strip back eight whole rows per instruction and stores
+    // 8 x 128 contiguous bytes.
+    char* const strip = lds + KC_XREG + wave * 4096;
+    const unsigned sw_off = (unsigned)pt * 128u;
+    const int srow = el >> 3, schunk = el & 7;
+    const unsigned sr_off = (unsigned)srow * 128u + 16u * (unsigned)(schunk ^ srow);       // + 1024 per pass (8 rows: same swizzle)
+    unsigned voC[2];                                                                       // per 32-column half (J % 16 == 0)
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+      voC[nj] = jw + 32 * nj + 16 * (schunk >> 2) < e->J ? (unsigned)srow * (unsigned)e->ldc * 4u + (unsigned)((jw >> 4) + 2 * nj) * 64u + 16u * (unsigned)schunk : OOBH;
+    const unsigned stepC8 = 8u * (unsigned)e->ldc * 4u;
+    auto strip_put = [&](int gg, const u32x4& hi, const u32x4& lo) {
+      *reinterpret_cast<u32x4*>(strip + sw_off + 16 * ((4 * gg + lh) ^ (pt & 7))) = hi;
+      *reinterpret_cast<u32x4*>(strip + sw_off + 16 * ((4 * gg + 2 + lh) ^ (pt & 7))) = lo;
+    };
+    // HAZARD (measured on gfx950, not modelled by hipcc): a ds_write_b128 can fetch its data registers AFTER a younger
+    // ds_read_b128 of the same wave has returned into them.  The compiler, free to do so, gave the read-back of the strip the
+    // registers of the planes it had just written; with the LDS busy (co-resident workgroup) single dwords of the written
+    // planes then held the read-back's data -- wrong values in ~1 % of the rows, different from run to run.  The planes of a
+    // half-block are therefore kept alive (keep_planes) until the read-back has been consumed.
+    auto keep_planes = [](const u32x4 (&hi)[2], const u32x4 (&lo)[2]) { asm volatile("" ::"v"(hi[0]), "v"(lo[0]), "v"(hi[1]), "v"(lo[1])); };
+    auto strip_flush = [&](int mi, int nj) {     // rows beyond I are rejected by the descriptor
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) {
+        const u32x4 d = *reinterpret_cast<const u32x4*>(strip + sr_off + 1024 * ps);
+        __builtin_amdgcn_raw_buffer_store_b128(d, srdC, voC[nj], (unsigned)(4 * mi + ps) * stepC8, 0);
       }
-      const char* hreg = lds + wave * 16384 + (mi & 1) * 8192;
-      const float okf = (32 * mi + pt) < nrows ? 1.f : 0.f;      // points beyond I: out of the maximum and the column sums
-      unsigned sword = 0u;
-      if (AUX == AUX_SINREC) sword = *reinterpret_cast<const unsigned*>(lds + KC_HSIGN + wave * 512 + (mi & 1) * 256 + lane * 4) ^ sflip;
-      u32x4 hh[4], hl[4];
-      if (AUX != AUX_NONE) {
+    };
+    float bj[4][8];
+    if (BIAS) {
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          hh[gq] = *reinterpret_cast<const u32x4*>(hreg + pt * 256 + 16 * ((4 * gq + lh) ^ (pt & 15)));
-          hl[gq] = *reinterpret_cast<const u32x4*>(hreg + pt * 256 + 16 * ((4 * gq + 2 + lh) ^ (pt & 15)));
+      for (int gq = 0; gq < 4; ++gq) {
+        const float4 b0 = *reinterpret_cast<const float4*>(&sbias[wj0 + 16 * gq + 8 * lh]);
+        const float4 b1 = *reinterpret_cast<const float4*>(&sbias[wj0 + 16 * gq + 8 * lh + 4]);
+        bj[gq][0] = b0.x; bj[gq][1] = b0.y; bj[gq][2] = b0.z; bj[gq][3] = b0.w;
+        bj[gq][4] = b1.x; bj[gq][5] = b1.y; bj[gq][6] = b1.z; bj[gq][7] = b1.w;
+      }
+    }
+
+    if constexpr (ONEPASS) {
+      // ---- sine: one pass.  u = acc * (2^-e w0 / pi) + b w0 / pi (bias row staged in LDS, already scaled)
+      const float su = inv_in * e->w0 * INV_PI;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        unsigned sw = 0u;
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) {
+          u32x4 phi[2], plo[2];
+#pragma unroll
+          for (int gg = 0; gg < 2; ++gg) {
+            const int gq = 2 * nj + gg;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = fmaf(acc[mi][nj][8 * gg + c], su, bj[gq][c]);
+            sinpi8<SIGNS, SINM>(v, sw);
+            split8(v, 8192.f, phi[gg], plo[gg]);
+            strip_put(gg, phi[gg], plo[gg]);
+          }
+          strip_flush(mi, nj);
+          keep_planes(phi, plo);
         }
-        if (mi + 2 < 4) {   // the region is free once these reads have returned
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hh[2]), "+v"(hh[3]), "+v"(hl[0]), "+v"(hl[1]), "+v"(hl[2]), "+v"(hl[3]), "+v"(sword)::"memory");
-          dma_h(mi + 2);
+        if (SIGNS && e->Csign != nullptr && wave_cols && 32 * mi < nrows)
+          e->Csign[((size_t)((c_i0 >> 5) + mi) * ((e->ldc + 63) >> 6) + ((e->c_col0 + jw) >> 6)) * 64 + el] = sw;
+      }
+      if ((wave & 1) == 0 && el == 0 && wave_cols) e->EC[(size_t)c_ti * ncb_of(e->ldc) + ((e->c_col0 + jw) >> 7)] = 13;
+    } else {
+      // ---- two passes.  Pass A: final values in place of the accumulators, their |max|, column sums -- one 32-column half
+      //      of the wave (nj) after the other, so that only 16 column sums are alive at a time.
+      float wmax = 0.f;
+      int eH = 0;
+      if (AUX != AUX_NONE && wave_cols) eH = e->EH[(size_t)c_ti * ncb_of(e->ldh) + ((e->h_col0 + jw) >> 7)];
+      const float inv_h = pow2f(-eH);
+      // Stored activations (derivative epilogues): half-block hb = (nj, mi) of the wave = 32 points x 128 B, fetched by LDS-DMA
+      // in four 1 KiB pieces (8 whole half-rows each) into one of two 4 KiB buffers of the wave (ring slot 2 / the region
+      // behind the ring), half-block hb + 1 while hb is worked on.  Chunk c of point row q lies at position c ^ ((q >> 1) & 7)
+      // (swizzle on the source address): the lanes of a ds_read_b128 group hold 16 points that differ in q & 15 -> 16
+      // different 16-byte slots of the 256-byte bank row.  The sign words (one dword per lane and block mi) come the same
+      // way, all four ahead of the first half-block.
+      const size_t offH = uniform_sz(AUX != AUX_NONE ? ((size_t)c_i0 * e->ldh + e->h_col0) * 4 : 0);
+      const srd_words srdH = make_srd_words(AUX != AUX_NONE ? e->H + offH : nullptr,
+                                            AUX != AUX_NONE ? clamp_bytes(((unsigned long long)(nrows - 1) * e->ldh + e->J) * 4ull) : 0u);
+      const unsigned hbuf[2] = {(unsigned)__builtin_amdgcn_readfirstlane(lds_addr(lds + 2 * KC_A + wave * 4096)),
+                                (unsigned)__builtin_amdgcn_readfirstlane(lds_addr(lds + KC_XREG + wave * 4096))};
+      const int hq = el >> 3;                                     // point row inside a piece
+      auto dma_h = [&](int hb) {
+        if (AUX == AUX_NONE) return;
+        const int nj = hb >> 2, mi = hb & 3;
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+          const int q = 8 * pc + hq;                              // point row inside the block
+          const int c = (el & 7) ^ ((q >> 1) & 7);                // chunk of the half-row this lane fetches
+          const bool ok = jw + 32 * nj + 16 * (c >> 2) < e->J;
+          const unsigned vo = ok ? (unsigned)q * (unsigned)e->ldh * 4u + (unsigned)((jw >> 4) + 2 * nj) * 64u + 16u * (unsigned)c : OOBH;
+          dma16_asm(srdH, hbuf[hb & 1] + (unsigned)(pc * 1024), vo, (unsigned)(32 * mi) * (unsigned)e->ldh * 4u);
+        }
+      };
+      if (AUX == AUX_SINREC) {
+        const srd_words srdS = make_srd_words(e->Hsign, clamp_bytes(sign_words((size_t)e->I, e->ldh) * 4ull));
+        const unsigned sreg0 = __builtin_amdgcn_readfirstlane(lds_addr(lds + KC_HSIGN + wave * 1024));
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const bool ok = wave_cols && 32 * mi < nrows;
+          const unsigned vo = ok ? (unsigned)((((size_t)((c_i0 >> 5) + mi) * ((e->ldh + 63) >> 6) + ((e->h_col0 + jw) >> 6)) * 64 + el) * 4) : OOBH;
+          dma4_asm(srdS, sreg0 + (unsigned)(mi * 256), vo, 0u);
         }
       }
+      dma_h(0);
+      dma_h(1);
+      // derivative epilogues: the accumulator's scale and |w0| in one factor; the sign bits are xor-ed with w0's own sign
+      const unsigned w0mag = __float_as_uint(fabsf(e->w0) * inv_in);
+      const unsigned sflip = e->w0 < 0.f ? 0xFFFFFFFFu : 0u;
+      unsigned sword[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj)
+      for (int nj = 0; nj < 2; ++nj) {
+        float cs[16];
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-          const int gq = 2 * nj + gg;
-          float v[8];
+        for (int r = 0; r < 16; ++r) cs[r] = 0.f;
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            const float x = acc[mi][nj][8 * gg + c];
-            v[c] = AUX == AUX_SINREC ? x : (AUX == AUX_NONE ? fmaf(x, inv_in, bj[gq][c]) : x * inv_in);
-          }
-          if (ACT == ACT_RELU) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
-          }
+        for (int mi = 0; mi < 4; ++mi) {
+          const int hb = 4 * nj + mi;
+          const float okf = (32 * mi + pt) < nrows ? 1.f : 0.f;      // points beyond I: out of the maximum and the column sums
+          u32x4 hh[2], hl[2];
           if (AUX != AUX_NONE) {
-            float h[8];
-            join8(hh[gq], hl[gq], inv_h, h);
-            if (AUX == AUX_SINREC) {
-              // w0 cos(w0 z) = +-|w0| sqrt(1 - h^2): the sign bit (xor-ed with w0's own sign, once per word) is shifted to bit
-              // 31 and merged over |w0| 2^-e by one v_bfi; 1 - h^2 is clamped at 0 by the FMA's output modifier
+            // half-block hb (and everything older: the sign words) is home when all but the four pieces of hb + 1 are
+            if (hb == 7) wait_vm<0>(); else wait_vm<4>();
+            const char* hreg = (hb & 1) ? lds + KC_XREG + wave * 4096 : lds + 2 * KC_A + wave * 4096;
+            if (AUX == AUX_SINREC && nj == 0) sword[mi] = *reinterpret_cast<const unsigned*>(lds + KC_HSIGN + wave * 1024 + mi * 256 + el * 4) ^ sflip;
 #pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                float om;
-                asm("v_fma_f32 %0, -%1, %1, 1.0 clamp" : "=v"(om) : "v"(h[c]));
-                unsigned w0s_bits;
-                asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(w0s_bits) : "s"(0x7fffffffu), "v"(w0mag), "v"(sword << (31 - (16 * nj + 8 * gg + c))));
-                v[c] *= __uint_as_float(w0s_bits) * __builtin_amdgcn_sqrtf(om);
-              }
-            } else {
-#pragma unroll
-              for (int c = 0; c < 8; ++c) v[c] = h[c] > 0.f ? v[c] : 0.f;
+            for (int gg = 0; gg < 2; ++gg) {
+              hh[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 128 + 16 * ((4 * gg + lh) ^ ((pt >> 1) & 7)));
+              hl[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 128 + 16 * ((4 * gg + 2 + lh) ^ ((pt >> 1) & 7)));
+            }
+            if (hb + 2 < 8) {   // the buffer is free once these reads have returned
+              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hl[0]), "+v"(hl[1]), "+v"(sword[mi])::"memory");
+              dma_h(hb + 2);
             }
           }
 #pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            if (COLSUM) cs[nj][8 * gg + c] = fmaf(v[c], okf, cs[nj][8 * gg + c]);
-            acc[mi][nj][8 * gg + c] = v[c];
+          for (int gg = 0; gg < 2; ++gg) {
+            const int gq = 2 * nj + gg;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const float x = acc[mi][nj][8 * gg + c];
+              v[c] = AUX == AUX_SINREC ? x : (BIAS ? fmaf(x, inv_in, bj[gq][c]) : x * inv_in);
+            }
+            if (ACT == ACT_RELU) {
+#pragma unroll
+              for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
+            }
+            if (AUX != AUX_NONE) {
+              float h[8];
+              join8(hh[gg], hl[gg], inv_h, h);
+              if (AUX == AUX_SINREC) {
+                // w0 cos(w0 z) = +-|w0| sqrt(1 - h^2): the sign bit (xor-ed with w0's own sign, once per word) is shifted to
+                // bit 31 and merged over |w0| 2^-e by one v_bfi; 1 - h^2 is clamped at 0 by the FMA's output modifier
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                  float om;
+                  asm("v_fma_f32 %0, -%1, %1, 1.0 clamp" : "=v"(om) : "v"(h[c]));
+                  unsigned w0s_bits;
+                  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(w0s_bits) : "s"(0x7fffffffu), "v"(w0mag), "v"(sword[mi] << (31 - (16 * nj + 8 * gg + c))));
+                  v[c] *= __uint_as_float(w0s_bits) * __builtin_amdgcn_sqrtf(om);
+                }
+              } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = h[c] > 0.f ? v[c] : 0.f;
+              }
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              if (COLSUM) cs[8 * gg + c] = fmaf(v[c], okf, cs[8 * gg + c]);
+              acc[mi][nj][8 * gg + c] = v[c];
+            }
+            if (jw + 16 * gq < e->J) wmax = fmaxf(wmax, okf * absmax3(v[6], v[7], absmax3(v[4], v[5], absmax3(v[2], v[3], absmax3(v[0], v[1], 0.f)))));
           }
-          if (jw + 16 * gq < p.J) wmax = fmaxf(wmax, okf * absmax3(v[6], v[7], absmax3(v[4], v[5], absmax3(v[2], v[3], absmax3(v[0], v[1], 0.f)))));
         }
-    }
-    if (COLSUM && p.colsum != nullptr) {   // one partial row per 128-point tile
+        if (COLSUM && e->colsum != nullptr) {   // one partial row per 128-point tile
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj)
+          for (int r = 0; r < 16; ++r) cs[r] = sum32(cs[r]);
+          if ((el & 31) == 31) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cs[nj][r] = sum32(cs[nj][r]);
-      if ((lane & 31) == 31) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-          if (jw + 16 * gq < p.J) {
-            float* d = p.colsum + (size_t)ti * p.ldcs + jw + 16 * gq + 8 * lh;
-            const int nj = gq >> 1, r0 = 8 * (gq & 1);
-            *reinterpret_cast<float4*>(d) = make_float4(cs[nj][r0], cs[nj][r0 + 1], cs[nj][r0 + 2], cs[nj][r0 + 3]);
-            *reinterpret_cast<float4*>(d + 4) = make_float4(cs[nj][r0 + 4], cs[nj][r0 + 5], cs[nj][r0 + 6], cs[nj][r0 + 7]);
+            for (int gg = 0; gg < 2; ++gg)
+              if (jw + 16 * (2 * nj + gg) < e->J) {
+                float* d = e->colsum + (size_t)c_ti * e->ldcs + jw + 16 * (2 * nj + gg) + 8 * lh;
+                *reinterpret_cast<float4*>(d) = make_float4(cs[8 * gg], cs[8 * gg + 1], cs[8 * gg + 2], cs[8 * gg + 3]);
+                *reinterpret_cast<float4*>(d + 4) = make_float4(cs[8 * gg + 4], cs[8 * gg + 5], cs[8 * gg + 6], cs[8 * gg + 7]);
+              }
           }
+        }
       }
-    }
-    // block maximum: waves 2 c and 2 c + 1 share the exponent block (ti, column block c of the tile)
+      // block maximum: waves 2 c and 2 c + 1 share the exponent block (ti, column block c of the tile)
+      wmax = wave_max(wmax);
+      if (el == 0) smax[wave] = wmax;
+      __syncthreads();   // also: every wave has finished with the stored-activation buffers the strips share
+      const float bmax = fmaxf(smax[wave & 2], smax[(wave & 2) + 1]);
+      const int eC = exp_of_maxbits(__float_as_uint(bmax));
+      const float sc = pow2f(eC);
+      if ((wave & 1) == 0 && el == 0 && wave_cols) e->EC[(size_t)c_ti * ncb_of(e->ldc) + ((e->c_col0 + jw) >> 7)] = eC;
+      if (more) headW();     // the registers of pass A are free: the next tile's first weight fragments go out ahead of the stores
+      // ---- pass B: split, through the strip, store
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o, 64));
-    if (lane == 0) smax[wave] = wmax;
-    __syncthreads();   // also: every wave has finished with the stored-activation regions the strips overlay
-    const float bmax = fmaxf(smax[wave & 2], smax[(wave & 2) + 1]);
-    const int eC = exp_of_maxbits(__float_as_uint(bmax));
-    const float sc = pow2f(eC);
-    if ((wave & 1) == 0 && lane == 0 && wave_cols) p.EC[(size_t)ti * ncb_of(p.ldc) + ((p.c_col0 + jw) >> 7)] = eC;
-    // ---- pass B: split, through the strip, store
+      for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+        for (int nj = 0; nj < 2; ++nj) {
+          u32x4 phi[2], plo[2];
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj)
+          for (int gg = 0; gg < 2; ++gg) {
+            float v[8];
 #pragma unroll
-        for (int gg = 0; gg < 2; ++gg) {
-          float v[8];
-#pragma unroll
-          for (int c = 0; c < 8; ++c) v[c] = acc[mi][nj][8 * gg + c];
-          u32x4 hi, lo;
-          split8(v, sc, hi, lo);
-          strip_put(2 * nj + gg, hi, lo);
+            for (int c = 0; c < 8; ++c) v[c] = acc[mi][nj][8 * gg + c];
+            split8(v, sc, phi[gg], plo[gg]);
+            strip_put(gg, phi[gg], plo[gg]);
+          }
+          strip_flush(mi, nj);
+          keep_planes(phi, plo);
         }
-      strip_flush(mi);
     }
+    if (!more) break;
+    vb = vbn;
+    first = false;
   }
 }
 
@@ -499,6 +603,18 @@ static int sin_mode() {   // SNERF_SIN=hw: v_sin_f32 instead of the polynomial (
   return m;
 }
 
+// workgroup slots of the device: two 256-thread workgroups per CU (registers, LDS).  SNERF_KC_GRID=<n> (tests) forces a
+// small grid so that small problems exercise the tile loop.  Read once: nothing here runs per launch.
+static int kc_slots() {
+  static const int n = [] {
+    if (const char* e = getenv("SNERF_KC_GRID")) { const int v = atoi(e); if (v > 0) return v; }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return 2 * cus;
+  }();
+  return n;
+}
+
 int launch_kc(const KcArgs& a0, hipStream_t st) {
   KcArgs a = a0;
   if (!a.A2) { a.A2 = a.A; a.EA2 = a.EA; a.lda2 = a.lda; a.a2_col0 = a.a_col0; if (a.Ka == 0) a.Ka = a.K; }
@@ -506,9 +622,11 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   if (rc) return rc;
   a.tiles_i = (a.I + 127) / 128;
   a.tiles_j = (a.J + 255) / 256;
-  const dim3 grid(a.tiles_i * a.tiles_j), block(256);
+  const int ntiles = a.tiles_i * a.tiles_j, slots = kc_slots();
+  const dim3 grid(ntiles < slots ? ntiles : slots), block(256);   // persistent workgroups, two per CU; tile = block + n * grid
   const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.K, 0, st);
   const bool cs = a.colsum != nullptr;
+  if (cs && a.bias != nullptr) { set_error("bsp gemm: bias and column sums in one launch"); return SNERF_ERR_BAD_DESC; }
 #define KC_LAUNCH(ACT_, AUX_, CS_, SG_, SM_) hipLaunchKernelGGL((gemm_kc_kernel<ACT_, AUX_, CS_, SG_, SM_>), grid, block, 0, st, a)
   if (a.aux_mode == AUX_SINREC) KC_LAUNCH(ACT_NONE, AUX_SINREC, true, false, SIN_POLY);
   else if (a.aux_mode == AUX_RELU_MASK) KC_LAUNCH(ACT_NONE, AUX_RELU_MASK, true, false, SIN_POLY);

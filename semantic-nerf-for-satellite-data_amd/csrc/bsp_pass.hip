@@ -33,6 +33,10 @@ void weights(bsp::KcArgs& g, const Plan& p, const float* pk, int job, int row0 =
 
 int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutputs* out, void* workspace, hipStream_t st) {
   const Ws ws{(char*)workspace};
+  // tile counters of the K-contiguous launches: one zeroed 64-byte slot per launch, in launch order
+  SNERF_HIP_CHECK(hipMemsetAsync(ws.c(p.o_kcq), 0, (size_t)KCQ_SLOTS * 64, st));
+  int kcq = 0;
+  auto launch_kc = [&](bsp::KcArgs& g) { g.tile_ctr = kcq < KCQ_SLOTS ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
   const int P = p.P, W = p.W, H = p.H;
   float* z = ws.f(p.o_z);
   // 1. depths
@@ -63,7 +67,7 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
     g.C = ws.c(p.o_h[i]); g.EC = ws.i(p.e_h[i]); g.ldc = W;
     g.bias = pk + p.b_tr[i]; g.act = act; g.w0 = (p.siren && i == 0) ? 30.f : 1.f;
     if (p.train && p.siren) g.Csign = ws.u(p.o_c[i]);
-    RC(bsp::launch_kc(g, st));
+    RC(launch_kc(g));
   }
   const char* hl = ws.c(p.o_h[p.L - 1]); const int* ehl = ws.i(p.e_h[p.L - 1]);
   {  // sigma pre-activation (rs_semantic.py:337) -> 32-wide fp32 buffer, column 0
@@ -76,7 +80,7 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
     bsp::KcArgs g;
     g.A = hl; g.EA = ehl; g.lda = W; g.Ka = W; weights(g, p, pk, p.wj_fs);
     g.I = P; g.J = W; g.K = W; g.C = ws.c(p.o_fa); g.EC = ws.i(p.e_fa); g.ldc = p.FA; g.bias = pk + p.b_fs;
-    RC(bsp::launch_kc(g, st));
+    RC(launch_kc(g));
   }
   const int r0 = p.sc ? p.sun_col : 0;
   {  // first layer of every head in one GEMM (sc pass: sun-visibility block only)
@@ -85,7 +89,7 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
     g.I = P; g.J = p.h1w; g.K = p.FA; g.C = ws.c(p.o_h1); g.EC = ws.i(p.e_h1); g.ldc = p.h1w;
     g.bias = pk + p.b_h1 + r0; g.act = act; g.w0 = 1.f;
     if (p.train && p.siren) g.Csign = ws.u(p.o_c1);
-    RC(bsp::launch_kc(g, st));
+    RC(launch_kc(g));
   }
   const int sun_col = p.sc ? 0 : p.sun_col;
   {  // sun visibility layers 2, 3 (rs_semantic.py:217-227)
@@ -93,11 +97,11 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
     g.A = ws.c(p.o_h1); g.EA = ws.i(p.e_h1); g.lda = p.h1w; g.a_col0 = sun_col; g.Ka = H; weights(g, p, pk, p.wj_s2);
     g.I = P; g.J = H; g.K = H; g.C = ws.c(p.o_s2); g.EC = ws.i(p.e_s2); g.ldc = H; g.bias = pk + p.b_s2; g.act = act;
     if (p.train && p.siren) g.Csign = ws.u(p.o_cs2);
-    RC(bsp::launch_kc(g, st));
+    RC(launch_kc(g));
     g.A = ws.c(p.o_s2); g.EA = ws.i(p.e_s2); g.lda = H; g.a_col0 = 0; weights(g, p, pk, p.wj_s3);
     g.C = ws.c(p.o_s3); g.EC = ws.i(p.e_s3); g.bias = pk + p.b_s3;
     if (p.train && p.siren) g.Csign = ws.u(p.o_cs3);
-    RC(bsp::launch_kc(g, st));
+    RC(launch_kc(g));
   }
   {  // sun visibility output pre-activation
     bsp::KcArgs g;
@@ -194,6 +198,9 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
                  void* workspace, hipStream_t st) {
   const Ws ws{(char*)workspace};
   const int P = p.P, W = p.W, H = p.H;
+  SNERF_HIP_CHECK(hipMemsetAsync(ws.c(p.o_kcq), 0, (size_t)KCQ_SLOTS * 64, st));
+  int kcq = 0;
+  auto launch_kc = [&](bsp::KcArgs& g) { g.tile_ctr = kcq < KCQ_SLOTS ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
   // activation derivative in a dX epilogue, rebuilt from the stored activation h (planes o_h / exponents e_h, leading
   // dimension ld, column col0): siren w0 * sign(cos) * sqrt(1 - h^2) with the sign words o_c; relu: h > 0
   auto dact = [&](bsp::KcArgs& g, size_t o_c, size_t o_h, size_t e_h, int ld, int col0 = 0, float w0 = 1.f) {
@@ -233,7 +240,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     g.I = P; g.J = p.KF; g.K = NARROW; g.C = dz1; g.EC = edz1; g.ldc = p.h1w;
     dact(g, p.o_c1, p.o_h1, p.e_h1, p.h1w);
     cs_ = colsum(g, p.KF);
-    RC(bsp::launch_kc(g, st));
+    RC(launch_kc(g));
     RC(bias_from_colsum(p, rq, cs_, p.KF, gp + p.b_h1));
   }
   {  // 2. sun visibility chain: output layer, layer 3, layer 2
@@ -247,7 +254,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     g.I = P; g.J = H; g.K = NARROW; g.C = ws.c(p.o_dsa); g.EC = ws.i(p.e_dsa); g.ldc = H;
     dact(g, p.o_cs3, p.o_s3, p.e_s3, H);
     cs_ = colsum(g, H);
-    RC(bsp::launch_kc(g, st));  // dz_s3
+    RC(launch_kc(g));  // dz_s3
     RC(bias_from_colsum(p, rq, cs_, H, gp + p.b_s3));
     RC(dw_gemm(p, mh, ws.c(p.o_dsa), ws.i(p.e_dsa), H, 0, H, false, ws.c(p.o_s2), ws.i(p.e_s2), H, 0, H, 0, st));
     RC(dw_reduce(rq, mh, (size_t)H * H, gp + p.w_s3));
@@ -255,7 +262,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     g.C = ws.c(p.o_dsb); g.EC = ws.i(p.e_dsb);
     dact(g, p.o_cs2, p.o_s2, p.e_s2, H);
     cs_ = colsum(g, H);
-    RC(bsp::launch_kc(g, st));  // dz_s2
+    RC(launch_kc(g));  // dz_s2
     RC(bias_from_colsum(p, rq, cs_, H, gp + p.b_s2));
     RC(dw_gemm(p, mh2, ws.c(p.o_dsb), ws.i(p.e_dsb), H, 0, H, false, ws.c(p.o_h1), ws.i(p.e_h1), p.h1w, sun_col, H, 0, st));
     RC(dw_reduce(rq, mh2, (size_t)H * H, gp + p.w_s2));
@@ -263,7 +270,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     g.C = dz1; g.EC = edz1; g.ldc = p.h1w; g.c_col0 = sun_col;
     dact(g, p.o_c1, p.o_h1, p.e_h1, p.h1w, sun_col);
     cs_ = colsum(g, H);
-    RC(bsp::launch_kc(g, st));  // dz1[:, sun block]
+    RC(launch_kc(g));  // dz1[:, sun block]
     RC(bias_from_colsum(p, rq, cs_, H, gp + p.b_h1 + (size_t)p.sun_col));
   }
   char* dfa = ws.c(p.o_dzb); int* edfa = ws.i(p.e_dzb);   // [P][FA]
@@ -276,7 +283,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     g.A = dz1; g.EA = edz1; g.lda = p.h1w; g.Ka = p.h1w; weights(g, p, pk, p.wj_th1, 0, r0);
     g.I = P; g.J = p.FA; g.K = p.h1w; g.C = dfa; g.EC = edfa; g.ldc = p.FA;
     cs_ = colsum(g, p.FA);   // columns [0, W) = bias gradient of feats_from_xyz
-    RC(bsp::launch_kc(g, st));
+    RC(launch_kc(g));
     RC(red_add_col(rq.col, cs_, (P + 127) / 128, (size_t)cs_ld(p.FA), W, gp + p.b_fs));
     if (d_t) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_t, p.N, p.S, p.tau, d_t, st));
     if (d_t_s && p.x_ts >= 0) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_ts, p.N, p.S, p.tau, d_t_s, st));
@@ -296,7 +303,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     g.C = dz; g.EC = edz; g.ldc = W;
     dact(g, p.o_c[p.L - 1], p.o_h[p.L - 1], p.e_h[p.L - 1], W, 0, (p.L == 1) ? 30.f : 1.f);
     cs_ = colsum(g, W);
-    RC(bsp::launch_kc(g, st));
+    RC(launch_kc(g));
     RC(bias_from_colsum(p, rq, cs_, W, gp + p.b_tr[p.L - 1]));
   }
   // 5. trunk, last layer to first
@@ -315,7 +322,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     g.I = P; g.J = W; g.K = W; g.C = dz_nxt; g.EC = edz_nxt; g.ldc = W;
     dact(g, p.o_c[i - 1], p.o_h[i - 1], p.e_h[i - 1], W, 0, (i - 1 == 0) ? 30.f : 1.f);
     cs_ = colsum(g, W);
-    RC(bsp::launch_kc(g, st));
+    RC(launch_kc(g));
     RC(bias_from_colsum(p, rq, cs_, W, gp + p.b_tr[i - 1]));
     char* t = dz_cur; dz_cur = dz_nxt; dz_nxt = t;
     int* te = edz_cur; edz_cur = edz_nxt; edz_nxt = te;

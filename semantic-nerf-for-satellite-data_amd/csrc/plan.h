@@ -62,6 +62,7 @@ struct Plan {
   // backward scratch
   size_t o_dza = 0, o_dzb = 0, o_dsa = 0, o_dsb = 0, o_dsig = 0, o_dfin = 0, o_dsun = 0;
   size_t o_colsum = 0, o_colsum2 = 0, o_slab = 0, o_slab2 = 0, o_skyslab = 0;
+  size_t o_kcq = 0;                 // tile counters of the K-contiguous launches: KCQ_SLOTS slots of 64 bytes, zeroed at the start of a pass
   size_t o_rq = 0, rq_floats = 0;   // reduction arena of the block-scaled plane backward (bsp_pass.hip: per-launch slabs / column-sum partials)
   // ---- block-scaled plane layout (fmt 1; csrc/bsp.h): every activation buffer above holds G16 planes instead of fp32
   //      (same bytes) and has an exponent table; the 32-wide head gradients also exist as planes
@@ -85,6 +86,7 @@ struct Plan {
   size_t ws_bytes = 0;
 };
 
+constexpr int KCQ_SLOTS = 64;
 struct DwSplit { int ns = 1; int k_split = 32; };
 DwSplit dw_choose(int P, int rows, int cols, bool narrow_rows);
 DwSplit dw_choose_bsp(int P, int rows, int cols, bool narrow_rows);

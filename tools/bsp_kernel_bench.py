@@ -31,11 +31,11 @@ H = torch.empty(P, W, device=dev)
 sign = torch.zeros((P // 32) * (W // 64) * 64, dtype=torch.int32, device=dev)
 cs = torch.zeros(P // 32, W, device=dev)
 for _ in range(reps if which in ("all", "kc", "fwd") else 1):   # forward SIREN layer
-    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), p(b), P, W, W, 0, 0, 1, 1.0, 0, None, None, p(H), p(sign),
+    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), None if which == "stamp" else p(b), P, W, W, 0, 0, 1, 1.0, 0, None, None, p(H), p(sign),
                                    p(cs) if which == "stamp" else None, 0, st), "fwd")
 if which == "stamp":   # ablation build -DBSP_ABL_STAMP: per-workgroup (start, loop end, end, HW_ID, XCC_ID) in the colsum buffer
     import numpy as np
-    d = cs.view(torch.int64).reshape(-1)[: 8 * 4096].reshape(4096, 8).cpu().numpy()
+    d = cs.view(torch.int64).reshape(-1)[: 8 * 4096 + 4 * 512].cpu().numpy()
     np.save(os.environ.get("STAMP_OUT", "gpurun_out/stamps.npy"), d)
 for _ in range(reps if which in ("plain",) else 0):   # forward layer without activation
     _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), p(b), P, W, W, 0, 0, 0, 1.0, 0, None, None, p(H), None, None, 0, st), "plain")
