@@ -68,7 +68,8 @@ def cpu_baseline(samples, seconds_budget=25.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, 16)  # the GPU box's CPU share for one GPU; more threads only oversubscribe the quota
+    affinity = cores
+    cores = min(cores, 16)  # the GPU box's CPU share for one GPU (16 cores); more threads only oversubscribe that quota
     torch.set_num_threads(cores)
     cfg = O.OracleCfg(n_samples=samples)
     n = 512
@@ -82,7 +83,8 @@ def cpu_baseline(samples, seconds_budget=25.0):
         O.train_step(p, emb, cfg, b, epoch=2)
         reps += 1
     dt = (time.time() - t0) / reps
-    return {"value": n / dt, "unit": "train rays/s", "cores": cores, "kind": "port",
+    return {"value": n / dt, "unit": "train rays/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "affinity_cores": affinity,
+            "threads_note": "torch intra-op threads = min(affinity, 16): one GPU's CPU share on the GPU box is 16 cores",
             "sample": f"{reps} full train steps (main+sc fwd, losses, bwd) of {n} rays x {samples} samples, "
                       f"fc_units=512, oracle/snerf_oracle.py on torch CPU fp32, {dt:.2f} s/step"}
 
@@ -144,6 +146,94 @@ def inference_rates(pipe, cfgs, device, samples, n_rays=40960 * 4):
                lean="rgb + depth + semantic_label, main pass only", batched="all results of render_rays incl. solar-correction pass")
     return out
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one GPU per LOCAL_RANK,
+    rendezvous on 127.0.0.1), relay rank 0's JSON line, fail if any rank fails.  Runs BEFORE this process touches the GPU
+    (a process that has initialised HIP must not exec or fork workers that use it), and never re-executes itself: the
+    children are ordinary subprocesses."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    import tempfile
+    procs = []
+    out0 = tempfile.TemporaryFile()
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    bad = []
+    while not bad and any(p.poll() is None for p in procs):   # a rank that dies leaves the others in a collective: end them
+        time.sleep(0.2)
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+    if bad:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()          # exactly the processes started above
+    for p in procs:
+        p.wait()
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
+    sys.stdout.flush()
+    if bad:
+        raise SystemExit(f"bench.py: rank(s) failed: {bad}")
+
+
+def rehearsal(args):
+    """The multi-rank protocol of the bench without the HIP path (CPU rigs, `--rehearsal`): rendezvous, warm-up, K timed
+    "steps" that are only the step's two collectives (16-float loss sums/counts, flat gradient bucket), barrier, max over
+    ranks, rank 0's JSON line.  Labelled as such: its `value` says nothing about the kernels."""
+    import torch.distributed as dist
+    from snerf_amd import parallel
+    if os.environ.get("SNERF_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):   # test hook: a rank that dies at start-up
+        raise SystemExit(3)
+    rank, world, device = parallel.init_distributed("gloo" if not torch.cuda.is_available() else None)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    bucket = torch.zeros(2_826_766 + 200, dtype=torch.float32)   # SURVEY 8(e): the flat gradient bucket
+    sums = torch.zeros(16, dtype=torch.float32)
+
+    def step():
+        parallel.allreduce_sum_(sums)
+        parallel.allreduce_sum_(bucket)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        dt = float(tmax.item())
+        print(json.dumps({
+            "metric": f"train rays/sec ({args.rays} rays x {args.samples} samples)", "value": args.rays * world * args.steps / dt, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "rehearsal (collectives only, no kernels)", "rehearsal": True,
+            "config": {"workload": "launch / rendezvous / collective protocol only", "rays_per_gpu": args.rays, "samples": args.samples,
+                       "global_batch": args.rays * world, "parallelism": f"dp{world}",
+                       "distributed": {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
+                                       "gradient_bucket_floats": int(bucket.numel())}}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -160,7 +250,12 @@ def main():
                          "modes of BASELINE configs[2]/[4] (reported under their own dtype, never as the fp32 headline)")
     ap.add_argument("--no-eager-gpu-baseline", action="store_true", help="skip the stock-PyTorch-on-GPU denominator (3 steps)")
     ap.add_argument("--no-inference", action="store_true", help="skip the forward-only (full-frame inference) leg")
+    ap.add_argument("--rehearsal", action="store_true", help="multi-rank protocol only (collectives, no kernels): CPU rigs")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)   # no launcher: be the launcher (before anything touches the GPU)
+    if args.rehearsal:
+        return rehearsal(args)
 
     import snerf_amd  # noqa: F401
     from snerf_amd import _lib, parallel
@@ -247,7 +342,7 @@ def main():
         # BASELINE.md holds no published number for this metric (the reference publishes none): null by the contract.  The
         # north-star ratio against the reference's single-GPU PyTorch path measured in THIS run is `vs_reference_gpu_eager`.
         "vs_baseline": None,
-        "dtype": reduced.get(mode, "f32"),
+        "dtype": reduced.get(mode, {"f16x2": "f32(f16x2)", "split3": "f32(bf16x3)"}.get(mode, "f32")),   # fp32-class arithmetic on 16-bit matrix cores: see `arithmetic`
         "arithmetic": {
             "f16x2": "fp32-class: activations stored as two fp16 planes with one power-of-two exponent per 128 x 128 block (same bytes as "
                      "fp32), products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate",
@@ -276,18 +371,24 @@ def main():
         ms, fl, n = prof.ms[0], prof.flops[0], prof.launches[0]
         alg = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0          # algorithmic: 2 I J K per launch (SURVEY 8d's FLOPs)
         mult, peak = ({"split3": 6.0, "f16x2": 3.0, "split2": 3.0, "bf16": 1.0, "split3_bwd2": 4.0}[mode], BF16_MFMA_PEAK_TFLOPS) if x6 else (1.0, FP32_MFMA_PEAK_TFLOPS)
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r02", "pmc_hbm_traffic.json")   # PMC passes of this workload (see the file's provenance)
-        if os.path.isfile(tf) and mode == "f16x2" and args.rays == 4096 and args.samples == 64:
-            try:
-                traffic = json.load(open(tf)).get("kc_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # HBM-side bytes per launch of the dominant kernel: NOT measured in this run (PMC passes need rocprofv3 runs of their own);
+        # read from the newest committed PMC summary of this workload, with its provenance next to it
+        traffic, traffic_source = None, None
+        for rr in ("r03", "r02"):
+            tf = os.path.join(ROOT, "profiles", rr, "pmc_hbm_traffic.json")
+            if os.path.isfile(tf) and mode == "f16x2" and args.rays == 4096 and args.samples == 64:
+                try:
+                    tj = json.load(open(tf))
+                    traffic = tj.get("kc_bytes_per_launch")
+                    traffic_source = {"file": f"profiles/{rr}/pmc_hbm_traffic.json", "commit": tj.get("commit"), "collected": tj.get("provenance", tj.get("note"))}
+                    break
+                except Exception:
+                    traffic = None
         line["roofline"] = {
             "bound": "mfma", "achieved": alg, "peak": peak, "unit": "TFLOP/s",
             "frac": alg / peak,                              # ALGORITHMIC fraction: SURVEY 8(d) FLOPs / dense 16-bit MFMA peak
             "frac_mfma_issued": alg * mult / peak,           # matrix-pipe occupancy: `mult` 16-bit MFMA products per fp32 product
-            "mfma_products_per_fp32_product": mult, "traffic": traffic,
+            "mfma_products_per_fp32_product": mult, "traffic": traffic, "traffic_source": traffic_source,
             "kernel": ("snerf::bsp::gemm_kc_kernel (128 x 256 tile; A = fp16 planes by LDS-DMA, W = fragment-ordered planes straight from L2; "
                        "3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block; epilogue writes planes + block exponents)" if mode == "f16x2" else
                        ("snerf::gemm_x6_kernel<false,true,NP,128> (split-bf16 planes from fp32 storage)" if x6 else

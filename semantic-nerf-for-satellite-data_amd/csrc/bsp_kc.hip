@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     tile_of_block(vb, tiles_i, tiles_j, ti, tj);
     i0 = ti * 128; j0 = tj * 256;
     const int lda = a->lda;
-    srdCur = make_srd(a->A + ((size_t)i0 * lda + a->a_col0) * 4, clamp_bytes(((unsigned long long)(a->I - i0 - 1) * lda + a->Ka) * 4ull));
+    srdCur = make_srd(a->A + ((size_t)i0 * lda + a->a_col0) * 4, (a->dbg & 1) ? 0u : clamp_bytes(((unsigned long long)(a->I - i0 - 1) * lda + a->Ka) * 4ull));
     sbias_st = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) voCur[q] = a_lane_off(q, lda, l);
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     const int jw = c_j0 + wj0;                                   // first column of the wave
     const bool wave_cols = jw < e->J;
     const size_t offC = uniform_sz(((size_t)c_i0 * e->ldc + e->c_col0) * 4);
-    const srd_t srdC = make_srd(e->C + offC, clamp_bytes(((unsigned long long)(nrows - 1) * e->ldc + e->J) * 4ull));
+    const srd_t srdC = make_srd(e->C + offC, (e->dbg & 4) ? 0u : clamp_bytes(((unsigned long long)(nrows - 1) * e->ldc + e->J) * 4ull));
     // Plane strip of one (32-point block, 32-column half) = [32 points][128 B]: the two 64-byte groups [hi | lo] of the
     // half as they lie in memory, chunk c at position c ^ (point & 7).  A el writes its 16-byte pieces (eight consecutive
     // lanes: eight positions = all 32 banks), then the wave reads the strip back eight whole rows per instruction and stores
@@ -622,6 +622,9 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   if (rc) return rc;
   a.tiles_i = (a.I + 127) / 128;
   a.tiles_j = (a.J + 255) / 256;
+  static const int dbg = [] { const char* e = getenv("SNERF_KC_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
+  if (dbg & 2) a.w_bytes = 0;
   const int ntiles = a.tiles_i * a.tiles_j, slots = kc_slots();
   const dim3 grid(ntiles < slots ? ntiles : slots), block(256);   // persistent workgroups, two per CU; tile = block + n * grid
   const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.K, 0, st);
