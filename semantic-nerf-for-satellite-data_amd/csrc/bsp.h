@@ -108,7 +108,7 @@ struct KcArgs {
   const char* H = nullptr; const int* EH = nullptr; int ldh = 0; int h_col0 = 0; const unsigned* Hsign = nullptr;
   float* colsum = nullptr; int ldcs = 0;   // partial column sums of the stored values, one row per 128-row tile (bias gradients)
   int tiles_i = 0, tiles_j = 0;
-  int dbg = 0;                       // timing-only diagnostics (SNERF_KC_DBG): 1 = no A traffic, 2 = no W traffic, 4 = no stores (zero-size descriptors)
+  int dbg = 0;                       // diagnostic builds only (bsp_kc.hip: DIAG); ignored by the product kernels
   int* tile_ctr = nullptr;           // 8 zeroed ints (one 64-byte slot per launch): tiles beyond the first are drawn from them; null: fixed shares
 };
 // sign word of (32-row block, 64-column group, lane) of a tensor with `ld` columns: bit 8 ps + c <-> row (lane >> 3) + 8 ps,

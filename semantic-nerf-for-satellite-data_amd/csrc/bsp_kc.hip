@@ -96,7 +96,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
-template <int ACT, int AUX, bool COLSUM, bool SIGNS, int SINM>
+// DIAG (tools/ablate/build_diag.sh only; the product instantiates DIAG = false): KcArgs::dbg removes operand traffic through
+// zero-size descriptors -- 1: A, 2: W (host side), 4: stores, 8: every tile reads the first 128 rows of A (always L2-resident).
+// Timing-only: the results are wrong.
+template <int ACT, int AUX, bool COLSUM, bool SIGNS, int SINM, bool DIAG = false>
 __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   // The arguments are read from the kernarg segment where they are needed (kargs(): a pointer the compiler must take as
   // new at every use site, so that it re-reads instead of keeping ~50 scalars alive across the k-loop and spilling them).
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     tile_of_block(vb, tiles_i, tiles_j, ti, tj);
     i0 = ti * 128; j0 = tj * 256;
     const int lda = a->lda;
-    srdCur = make_srd(a->A + ((size_t)i0 * lda + a->a_col0) * 4, (a->dbg & 1) ? 0u : clamp_bytes(((unsigned long long)(a->I - i0 - 1) * lda + a->Ka) * 4ull));
+    const int i0a = (DIAG && (a->dbg & 8)) ? 0 : i0;
+    srdCur = make_srd(a->A + ((size_t)i0a * lda + a->a_col0) * 4, (DIAG && (a->dbg & 1)) ? 0u : clamp_bytes(((unsigned long long)(a->I - i0a - 1) * lda + a->Ka) * 4ull));
     sbias_st = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) voCur[q] = a_lane_off(q, lda, l);
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     const int jw = c_j0 + wj0;                                   // first column of the wave
     const bool wave_cols = jw < e->J;
     const size_t offC = uniform_sz(((size_t)c_i0 * e->ldc + e->c_col0) * 4);
-    const srd_t srdC = make_srd(e->C + offC, (e->dbg & 4) ? 0u : clamp_bytes(((unsigned long long)(nrows - 1) * e->ldc + e->J) * 4ull));
+    const srd_t srdC = make_srd(e->C + offC, (DIAG && (e->dbg & 4)) ? 0u : clamp_bytes(((unsigned long long)(nrows - 1) * e->ldc + e->J) * 4ull));
     // Plane strip of one (32-point block, 32-column half) = [32 points][128 B]: the two 64-byte groups [hi | lo] of the
     // half as they lie in memory, chunk c at position c ^ (point & 7).  A el writes its 16-byte pieces (eight consecutive
     // lanes: eight positions = all 32 banks), then the wave reads the strip back eight whole rows per instruction and stores
@@ -598,8 +602,8 @@ int prof_hook_begin(double flops, int variant, hipStream_t st);   // gemm.hip: p
 void prof_hook_end(int token, hipStream_t st);
 int check_kc(const KcArgs& a, bool narrow);                        // bsp_gemm.hip
 
-static int sin_mode() {   // SNERF_SIN=hw: v_sin_f32 instead of the polynomial (diagnostic A/B; read once)
-  static const int m = [] { const char* e = getenv("SNERF_SIN"); return (e && e[0] == 'h') ? SIN_HW : SIN_POLY; }();
+static int sin_mode() {   // SNERF_SIN=poly: the polynomial instead of v_sin_f32 (A/B; read once)
+  static const int m = [] { const char* e = getenv("SNERF_SIN"); return (e && e[0] == 'p') ? SIN_POLY : SIN_HW; }();
   return m;
 }
 
@@ -622,15 +626,20 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   if (rc) return rc;
   a.tiles_i = (a.I + 127) / 128;
   a.tiles_j = (a.J + 255) / 256;
+#ifdef KC_DIAG_BUILD
+  constexpr bool DIAG = true;
   static const int dbg = [] { const char* e = getenv("SNERF_KC_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
   if (dbg & 2) a.w_bytes = 0;
+#else
+  constexpr bool DIAG = false;
+#endif
   const int ntiles = a.tiles_i * a.tiles_j, slots = kc_slots();
   const dim3 grid(ntiles < slots ? ntiles : slots), block(256);   // persistent workgroups, two per CU; tile = block + n * grid
   const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.K, 0, st);
   const bool cs = a.colsum != nullptr;
   if (cs && a.bias != nullptr) { set_error("bsp gemm: bias and column sums in one launch"); return SNERF_ERR_BAD_DESC; }
-#define KC_LAUNCH(ACT_, AUX_, CS_, SG_, SM_) hipLaunchKernelGGL((gemm_kc_kernel<ACT_, AUX_, CS_, SG_, SM_>), grid, block, 0, st, a)
+#define KC_LAUNCH(ACT_, AUX_, CS_, SG_, SM_) hipLaunchKernelGGL((gemm_kc_kernel<ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a)
   if (a.aux_mode == AUX_SINREC) KC_LAUNCH(ACT_NONE, AUX_SINREC, true, false, SIN_POLY);
   else if (a.aux_mode == AUX_RELU_MASK) KC_LAUNCH(ACT_NONE, AUX_RELU_MASK, true, false, SIN_POLY);
   else if (a.act == ACT_SIN) {
