@@ -152,6 +152,9 @@ const char* snerf_last_error(void);
 /* ---- sizes (host-side, no GPU work) -------------------------------------------------------------- */
 /* number of floats of the packed parameter / packed gradient buffer */
 size_t snerf_packed_floats(const SnerfDesc* desc);
+/* floats of a packed GRADIENT buffer: the leading fp32 region of the packed layout -- all that snerf_backward accumulates
+ * into and snerf_unpack_grads reads (the weight-operand packs behind it exist for parameters only) */
+size_t snerf_grad_floats(const SnerfDesc* desc);
 /* workspace bytes for one pass (activations + scratch) under desc->flags; the same buffer must be
  * handed to snerf_backward for that pass */
 size_t snerf_workspace_bytes(const SnerfDesc* desc);

@@ -116,6 +116,8 @@ def lib():
     L.snerf_last_error.restype = C.c_char_p
     L.snerf_packed_floats.restype = C.c_size_t
     L.snerf_packed_floats.argtypes = [C.POINTER(SnerfDesc)]
+    L.snerf_grad_floats.restype = C.c_size_t
+    L.snerf_grad_floats.argtypes = [C.POINTER(SnerfDesc)]
     L.snerf_workspace_bytes.restype = C.c_size_t
     L.snerf_workspace_bytes.argtypes = [C.POINTER(SnerfDesc)]
     L.snerf_pack_params.restype = C.c_int
@@ -171,7 +173,7 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed (code {rc}): {lib().snerf_last_error().decode()}")
 
 
-EXPORTED_SYMBOLS = ("snerf_version", "snerf_last_error", "snerf_packed_floats", "snerf_workspace_bytes",
+EXPORTED_SYMBOLS = ("snerf_version", "snerf_last_error", "snerf_packed_floats", "snerf_grad_floats", "snerf_workspace_bytes",
                     "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward", "snerf_test_gemm",
                     "snerf_loss_workspace_bytes", "snerf_loss_partial", "snerf_loss_finish", "snerf_profile_begin",
                     "snerf_profile_end", "snerf_sample_z", "snerf_adam_step", "snerf_test_bsp_roundtrip", "snerf_test_bsp_kc",

@@ -661,6 +661,12 @@ size_t snerf_packed_floats(const SnerfDesc* desc) {
   return p.packed_floats;
 }
 
+size_t snerf_grad_floats(const SnerfDesc* desc) {
+  Plan p;
+  if (make_plan(desc, &p)) return 0;
+  return p.n_fp32;
+}
+
 size_t snerf_workspace_bytes(const SnerfDesc* desc) {
   Plan p;
   if (make_plan(desc, &p)) return 0;
@@ -675,7 +681,7 @@ int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* p
   build_tables(p, params, tb);
   if (tb.missing) { set_error("snerf_pack_params: a parameter tensor required by this SnerfDesc is NULL"); return SNERF_ERR_NULL; }
   hipStream_t st = (hipStream_t)stream;
-  SNERF_HIP_CHECK(hipMemsetAsync(packed, 0, p.n_fp32 * sizeof(float), st));
+  RC(launch_zero_bytes(packed, p.n_fp32 * sizeof(float), st));
   for (int i = 0; i < tb.nt; ++i) RC(launch_copy_table(tb.tabs[i], packed, 0, st));
   if (p.fmt == 1) {
     // default arithmetic: every weight operand (matrix or its transpose) as a fragment-ordered fp16-plane pack with one

@@ -22,6 +22,7 @@ struct CopyEntry {
 constexpr int COPY_TABLE_MAX = 40;
 struct CopyTable { CopyEntry e[COPY_TABLE_MAX]; int n; };
 
+int launch_zero_bytes(void* p, size_t bytes, hipStream_t st);   // bytes % 4 == 0; a kernel, not a memset node (see aux_kernels.hip)
 int launch_sample_z(const float* rays, const float* zsteps, const float* u, float* z, int N, int S, hipStream_t st);
 int launch_encode(const EncodeArgs& a, hipStream_t st);
 int launch_copy_table(const CopyTable& tb, float* packed, int mode, hipStream_t st);
@@ -33,7 +34,9 @@ int reduce_partials(const float* in, int n_in, size_t in_stride, int width, floa
 // batched reductions (aux_kernels.hip): out[e] += sum_q in[q * stride + e], all jobs of a pass in two launches
 struct RedJob { const float* in; float* out; unsigned long long stride; long long width; int n_in; int blk0; int vec; int pad; };
 constexpr int RED_MAX = 56;
-struct RedTable { RedJob j[RED_MAX]; int n = 0; int blocks = 0; };
+struct RedTable { RedJob j[RED_MAX]; int n = 0; int blocks = 0; };      // host-side queue
+constexpr int RED_CHUNK = 24;
+struct RedChunk { RedJob j[RED_CHUNK]; int n = 0; };                      // what one launch carries as its argument
 int red_add_elem(RedTable& tb, const float* in, int n_in, size_t stride, size_t width, float* out);   // few slabs, many elements
 int red_add_col(RedTable& tb, const float* in, int n_in, size_t stride, int width, float* out);       // many partial rows, <= ~1024 columns
 int launch_reductions(const RedTable& elem, const RedTable& col, hipStream_t st);

@@ -248,6 +248,22 @@ int reduce_partials(const float* in, int n_in, size_t in_stride, int width, floa
   return 0;
 }
 
+// ---- zero fill ---------------------------------------------------------------------------------------------------------
+// A kernel instead of hipMemsetAsync wherever a hot call clears device memory: the memset NODES those calls leave in a
+// captured HIP graph did not reproduce the eager calls on ROCm 7.2 (first replay right, later replays with stale
+// contents; tools/ablate/graph_probe.py).  4-byte granularity.
+__global__ void zero_words_kernel(unsigned* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+int launch_zero_bytes(void* p, size_t bytes, hipStream_t st) {
+  const size_t n = bytes / 4;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (unsigned*)p, n);
+  SNERF_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- per-ray embedding rows ---------------------------------------------------------------------------------------
 __global__ void embedding_rows_kernel(const float* __restrict__ table, int n_embed, int tau, const long long* __restrict__ idx,
                                       int n, float* __restrict__ rows) {
@@ -255,7 +271,7 @@ __global__ void embedding_rows_kernel(const float* __restrict__ table, int n_emb
   if (i >= n * tau) return;
   const int r = i / tau, c = i - r * tau;
   const long long v = idx[r];
-  if (v < 0 || v >= n_embed) { rows[i] = 0.f; return; }
+  if (v < 0 || v >= n_embed) { rows[i] = __builtin_nanf(""); return; }   // torch's nn.Embedding raises; a kernel cannot: NaN rows (as the label path does)
   rows[i] = table[(size_t)v * tau + c];
 }
 // one workgroup per table row v: thread t adds the rays t, t + 256, ... that index v (ascending), then the 256 partial
@@ -293,7 +309,7 @@ int launch_embedding_backward(const long long* idx, const float* d_rows, int n, 
 // out[e] += sum_{q < n_in} in[q * stride + e]; job tables travel as kernel arguments.  Fixed order -> deterministic.
 // "elem" jobs (dW split slabs: few rows, many elements): a thread owns four consecutive elements (or one, `vec` = 0) and
 // walks the slabs; "col" jobs (column-sum partials: thousands of rows, <= 1024 columns): reduce_cols_kernel's scheme.
-__global__ __launch_bounds__(256) void reduce_elem_jobs_kernel(const RedTable tb) {
+__global__ __launch_bounds__(256) void reduce_elem_jobs_kernel(const RedChunk tb) {
   int k = 0;
   while (k + 1 < tb.n && (int)blockIdx.x >= tb.j[k + 1].blk0) ++k;
   const RedJob jb = tb.j[k];
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(256) void reduce_elem_jobs_kernel(const RedTable tb
   }
 }
 
-__global__ __launch_bounds__(256) void reduce_col_jobs_kernel(const RedTable tb) {
+__global__ __launch_bounds__(256) void reduce_col_jobs_kernel(const RedChunk tb) {
   __shared__ float part[16][17];
   int k = 0;
   while (k + 1 < tb.n && (int)blockIdx.x >= tb.j[k + 1].blk0) ++k;
@@ -367,9 +383,24 @@ int red_add_col(RedTable& tb, const float* in, int n_in, size_t stride, int widt
   tb.blocks += (width + 15) / 16;
   return 0;
 }
+// The job tables travel as kernel arguments in chunks of RED_CHUNK jobs (~1.2 KB): by-value arguments beyond ~2 KB did not
+// survive capture in a HIP graph on ROCm 7.2 (replays read a corrupt table -> wild addresses; the eager launch was fine).
+template <class K>
+static int launch_red_chunks(K kernel, const RedTable& tb, hipStream_t st) {
+  for (int first = 0; first < tb.n; first += RED_CHUNK) {
+    RedChunk c;
+    c.n = tb.n - first < RED_CHUNK ? tb.n - first : RED_CHUNK;
+    const int b0 = tb.j[first].blk0;
+    for (int i = 0; i < c.n; ++i) { c.j[i] = tb.j[first + i]; c.j[i].blk0 -= b0; }
+    const int b1 = first + c.n < tb.n ? tb.j[first + c.n].blk0 : tb.blocks;
+    hipLaunchKernelGGL(kernel, dim3(b1 - b0), dim3(256), 0, st, c);
+    SNERF_LAUNCH_CHECK();
+  }
+  return 0;
+}
 int launch_reductions(const RedTable& elem, const RedTable& col, hipStream_t st) {
-  if (elem.n > 0) { hipLaunchKernelGGL(reduce_elem_jobs_kernel, dim3(elem.blocks), dim3(256), 0, st, elem); SNERF_LAUNCH_CHECK(); }
-  if (col.n > 0) { hipLaunchKernelGGL(reduce_col_jobs_kernel, dim3(col.blocks), dim3(256), 0, st, col); SNERF_LAUNCH_CHECK(); }
+  if (elem.n > 0) { int rc = launch_red_chunks(reduce_elem_jobs_kernel, elem, st); if (rc) return rc; }
+  if (col.n > 0) { int rc = launch_red_chunks(reduce_col_jobs_kernel, col, st); if (rc) return rc; }
   return 0;
 }
 

@@ -144,7 +144,9 @@ struct WPackJob {        // one weight operand: fp32 master matrix (possibly rea
   int m_rows, m_cols;           // extent of the master matrix (for the |max| pass)
 };
 constexpr int WPACK_MAX = 48;
-struct WPackTable { WPackJob j[WPACK_MAX]; int n; };
+struct WPackTable { WPackJob j[WPACK_MAX]; int n; };      // host-side table
+constexpr int WPACK_CHUNK = 24;
+struct WPackChunk { WPackJob j[WPACK_CHUNK]; int n; };   // what one launch carries as its argument
 __host__ __device__ inline size_t wp16_bytes(int rows, int K) { return (size_t)((rows + 31) / 32) * (size_t)(K / 16) * 2048; }
 int launch_wpack(const WPackTable& tb, const float* master, char* planes, int* exps, unsigned* maxbits, hipStream_t st);
 
@@ -153,6 +155,7 @@ struct EncodeArgs;
 namespace bsp {
 // x = o + d z, gamma(x) (or raw x) as planes [P][Ep]; the [sun | t | t_s] block as columns [fa_col0, +16) of the [P][FA] tensor
 int launch_encode_bsp(const EncodeArgs& a, char* pe, int* Epe, char* fa, int* Efa, int fa_col0, hipStream_t st);
+int launch_zero_cols(char* base, size_t pitch, size_t width_bytes, int rows, hipStream_t st);   // width_bytes % 16 == 0
 int launch_ray_sum_bsp(const char* dfa, const int* E, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st);
 // [rows][32] fp32 -> 256-row partial column sums (+ planes [rows][32] and one exponent per 128 rows when planes != null)
 int launch_colsum32_bsp(const float* in, int rows, float* partial, char* planes, int* E, hipStream_t st);

@@ -84,7 +84,7 @@ int launch_from_planes(const char* src, const int* E, int ld, int col0, int rows
 // pass 1: |max| of every master matrix (float bits, atomicMax: order-independent); pass 2: every operand (a matrix or its
 // transpose) into WF16 units of 32 rows x 16 k = 2 KiB = [plane][lane][8 fp16] with lane = 32 (k / 8) + row: the B operand
 // fragment of v_mfma_f32_32x32x16_f16 for 32 output columns, one contiguous KiB per plane.
-__global__ __launch_bounds__(256) void wmax_kernel(WPackTable tb, const float* __restrict__ master, unsigned* __restrict__ maxbits) {
+__global__ __launch_bounds__(256) void wmax_kernel(WPackChunk tb, const float* __restrict__ master, unsigned* __restrict__ maxbits) {
   const WPackJob j = tb.j[blockIdx.y];
   if (j.transposed) return;            // its matrix is covered by the non-transposed job with the same exponent slot
   const size_t n = (size_t)j.m_rows * j.m_cols;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void wmax_kernel(WPackTable tb, const float* _
   if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(maxbits + j.e_idx, __float_as_uint(m));
 }
 
-__global__ __launch_bounds__(256) void wpack_kernel(WPackTable tb, const float* __restrict__ master, char* __restrict__ planes,
+__global__ __launch_bounds__(256) void wpack_kernel(WPackChunk tb, const float* __restrict__ master, char* __restrict__ planes,
                                                     int* __restrict__ exps, const unsigned* __restrict__ maxbits) {
   const WPackJob j = tb.j[blockIdx.y];
   const int rb32 = (j.rows + 31) >> 5, nks = j.K >> 4;
@@ -127,10 +127,34 @@ __global__ __launch_bounds__(256) void wpack_kernel(WPackTable tb, const float* 
 
 int launch_wpack(const WPackTable& tb, const float* master, char* planes, int* exps, unsigned* maxbits, hipStream_t st) {
   if (tb.n <= 0) return SNERF_OK;
-  SNERF_HIP_CHECK(hipMemsetAsync(maxbits, 0, WPACK_MAX * sizeof(unsigned), st));
-  hipLaunchKernelGGL(wmax_kernel, dim3(32, tb.n), dim3(256), 0, st, tb, master, maxbits);
-  SNERF_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wpack_kernel, dim3(128, tb.n), dim3(256), 0, st, tb, master, planes, exps, maxbits);
+  { int rc = launch_zero_bytes(maxbits, WPACK_MAX * sizeof(unsigned), st); if (rc) return rc; }
+  // the table travels in chunks of WPACK_CHUNK jobs: by-value kernel arguments beyond ~2 KB did not survive capture in a HIP
+  // graph on ROCm 7.2 (aux_kernels.hip: launch_red_chunks).  All maxima first: a transposed job shares its matrix's slot.
+  for (int pass = 0; pass < 2; ++pass)
+    for (int first = 0; first < tb.n; first += WPACK_CHUNK) {
+      WPackChunk c;
+      c.n = tb.n - first < WPACK_CHUNK ? tb.n - first : WPACK_CHUNK;
+      for (int i = 0; i < c.n; ++i) c.j[i] = tb.j[first + i];
+      if (pass == 0) hipLaunchKernelGGL(wmax_kernel, dim3(32, c.n), dim3(256), 0, st, c, master, maxbits);
+      else hipLaunchKernelGGL(wpack_kernel, dim3(128, c.n), dim3(256), 0, st, c, master, planes, exps, maxbits);
+      SNERF_LAUNCH_CHECK();
+    }
+  return SNERF_OK;
+}
+
+// zero `width` bytes (a multiple of 16) of every row of a pitched region: the pad columns between feats and extras of narrow
+// networks.  (A kernel, not hipMemset2DAsync: the memset node that call leaves in a captured hipGraph did not reproduce the
+// eager call on ROCm 7.2 -- replays zeroed the tensor beside the pad columns.)
+__global__ void zero_cols_kernel(char* base, size_t pitch, int width16, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * width16) return;
+  const int r = i / width16, c = i - r * width16;
+  *reinterpret_cast<u32x4*>(base + (size_t)r * pitch + 16 * (size_t)c) = u32x4{0u, 0u, 0u, 0u};
+}
+int launch_zero_cols(char* base, size_t pitch, size_t width_bytes, int rows, hipStream_t st) {
+  const int w16 = (int)(width_bytes / 16);
+  if (w16 <= 0 || rows <= 0) return SNERF_OK;
+  hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)(((size_t)rows * w16 + 255) / 256)), dim3(256), 0, st, base, pitch, w16, rows);
   SNERF_LAUNCH_CHECK();
   return SNERF_OK;
 }

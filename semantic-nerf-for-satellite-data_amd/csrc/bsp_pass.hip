@@ -13,6 +13,8 @@ namespace snerf {
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 namespace {
+// SNERF_KC_STATIC=1 (diagnostic): fixed tile shares instead of the per-launch tile counters
+bool kc_static_tiles() { static const bool v = [] { const char* e = getenv("SNERF_KC_STATIC"); return e && e[0] == '1'; }(); return v; }
 struct Ws {
   char* base;
   char* c(size_t off) const { return base + off; }
@@ -33,10 +35,12 @@ void weights(bsp::KcArgs& g, const Plan& p, const float* pk, int job, int row0 =
 
 int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutputs* out, void* workspace, hipStream_t st) {
   const Ws ws{(char*)workspace};
-  // tile counters of the K-contiguous launches: one zeroed 64-byte slot per launch, in launch order
-  SNERF_HIP_CHECK(hipMemsetAsync(ws.c(p.o_kcq), 0, (size_t)KCQ_SLOTS * 64, st));
+  // tile counters of the K-contiguous launches: one zeroed 64-byte slot per launch, in launch order.  (Zeroed by a kernel:
+  // with hipMemsetAsync the forward's and the backward's memset of this region became two identical memset nodes of a
+  // captured HIP graph, and replays on ROCm 7.2 then ran the backward's launches on counters that had not been zeroed.)
+  RC(bsp::launch_zero_cols(ws.c(p.o_kcq), (size_t)KCQ_SLOTS * 64, (size_t)KCQ_SLOTS * 64, 1, st));
   int kcq = 0;
-  auto launch_kc = [&](bsp::KcArgs& g) { g.tile_ctr = kcq < KCQ_SLOTS ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
+  auto launch_kc = [&](bsp::KcArgs& g) { g.tile_ctr = (kcq < KCQ_SLOTS && !kc_static_tiles()) ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
   const int P = p.P, W = p.W, H = p.H;
   float* z = ws.f(p.o_z);
   // 1. depths
@@ -52,7 +56,7 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
   ea.FA = p.FA; ea.W = p.Wf; ea.Xp = p.Xp; ea.x_sun = p.x_sun; ea.x_t = p.x_t; ea.x_ts = p.x_ts; ea.tau = p.tau;
   RC(bsp::launch_encode_bsp(ea, ws.c(p.o_pe), ws.i(p.e_pe), ws.c(p.o_fa), ws.i(p.e_fa), p.Wf, st));
   if (p.Wf > W)   // pad columns between feats and extras (narrow test networks only): zero planes, read against zero weights
-    SNERF_HIP_CHECK(hipMemset2DAsync(ws.c(p.o_fa) + (size_t)W * 4, (size_t)p.FA * 4, 0, (size_t)(p.Wf - W) * 4, P, st));
+    RC(bsp::launch_zero_cols(ws.c(p.o_fa) + (size_t)W * 4, (size_t)p.FA * 4, (size_t)(p.Wf - W) * 4, P, st));
   // 3. trunk (rs_semantic.py:325-334)
   const int act = p.siren ? ACT_SIN : ACT_RELU;
   for (int i = 0; i < p.L; ++i) {
@@ -198,9 +202,9 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
                  void* workspace, hipStream_t st) {
   const Ws ws{(char*)workspace};
   const int P = p.P, W = p.W, H = p.H;
-  SNERF_HIP_CHECK(hipMemsetAsync(ws.c(p.o_kcq), 0, (size_t)KCQ_SLOTS * 64, st));
+  RC(bsp::launch_zero_cols(ws.c(p.o_kcq), (size_t)KCQ_SLOTS * 64, (size_t)KCQ_SLOTS * 64, 1, st));
   int kcq = 0;
-  auto launch_kc = [&](bsp::KcArgs& g) { g.tile_ctr = kcq < KCQ_SLOTS ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
+  auto launch_kc = [&](bsp::KcArgs& g) { g.tile_ctr = (kcq < KCQ_SLOTS && !kc_static_tiles()) ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
   // activation derivative in a dX epilogue, rebuilt from the stored activation h (planes o_h / exponents e_h, leading
   // dimension ld, column col0): siren w0 * sign(cos) * sqrt(1 - h^2) with the sign words o_c; relu: h > 0
   auto dact = [&](bsp::KcArgs& g, size_t o_c, size_t o_h, size_t e_h, int ld, int col0 = 0, float w0 = 1.f) {

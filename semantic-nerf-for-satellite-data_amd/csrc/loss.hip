@@ -231,7 +231,7 @@ int snerf_loss_partial(const SnerfLossCfg* cfg, const SnerfLossIn* in, float* to
   float* tmp = partial + (size_t)blocks * 4 * SNERF_LOSS_NTOT;
   hipLaunchKernelGGL(loss_partial_kernel, dim3(blocks), dim3(256), 0, st, *cfg, *in, partial);
   SNERF_LAUNCH_CHECK();
-  SNERF_HIP_CHECK(hipMemsetAsync(totals, 0, SNERF_LOSS_NTOT * sizeof(float), st));
+  { int rc = launch_zero_bytes(totals, SNERF_LOSS_NTOT * sizeof(float), st); if (rc) return rc; }
   return reduce_partials(partial, blocks * 4, SNERF_LOSS_NTOT, SNERF_LOSS_NTOT, tmp, totals, st);
 }
 

@@ -11,7 +11,7 @@ import time
 
 import torch
 
-from .. import parallel
+from .. import ops, parallel
 
 
 class Pipeline(torch.nn.Module):
@@ -131,7 +131,8 @@ class TrainLoop:
             batch["depth"] = pl.datasets["depth"].batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)
         self.optimizer.zero_grad()
         out = pl.training_step(batch, step)
-        out["loss"].backward()
+        with ops.accumulate_into_sinks():   # a plain accumulate-into-.grad backward: the passes may write the optimiser's bucket directly
+            out["loss"].backward()
         if hasattr(self.optimizer, "flat_g"):
             # every .grad is a view of the optimiser's flat gradient buffer: it is the all-reduce bucket
             self.optimizer._collect_foreign_grads()

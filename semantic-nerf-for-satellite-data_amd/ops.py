@@ -13,6 +13,8 @@ import torch
 import os
 import weakref
 
+_WS_POISON = os.environ.get("SNERF_WS_POISON", "0") == "1"
+
 from . import _lib
 
 # SNERF_MFMA=f16x2|split3|fp32|split3_bwd2|split2|bf16 overrides every ModelSpec.mfma (diagnostics, bench.py --mfma);
@@ -131,6 +133,22 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _empty(*a, **k):
+    """torch.empty; with SNERF_WS_POISON=1 (diagnostic) filled with 0xFF bytes, so that a kernel which reads bytes nobody
+    wrote shows up as NaN / a wild value instead of depending on what the allocator happens to hand out"""
+    t = torch.empty(*a, **k)
+    if _WS_POISON:
+        t.view(torch.uint8).fill_(0xFF) if t.numel() else None
+    return t
+
+
+def _empty_like(x):
+    t = torch.empty_like(x)
+    if _WS_POISON and t.numel():
+        t.view(torch.uint8).fill_(0xFF)
+    return t
+
+
 # ---- gradient sinks -------------------------------------------------------------------------------------------------
 # A parameter may have a registered SINK: a preallocated gradient tensor (FlatAdam's view into its flat bucket, which is
 # also p.grad).  A pass whose parameters all have one accumulates its packed gradients straight into the sinks
@@ -186,8 +204,32 @@ def _queue_sink_sync(dev):
         pass
 
 
+_SINKS_ACTIVE = False
+
+
+class accumulate_into_sinks:
+    """`with ops.accumulate_into_sinks(): loss.backward()` -- only inside this context do the passes add their parameter
+    gradients straight into the registered sink tensors (and hand autograd None for them).  It is the training loop's
+    statement that this backward is a plain accumulate-into-.grad one.  Anywhere else -- torch.autograd.grad,
+    backward(inputs=...), gradient checks -- the passes return ordinary gradients and touch no .grad.  Entering also
+    discards a stale end-of-backward marker that a backward which raised may have left behind."""
+
+    def __enter__(self):
+        global _SINKS_ACTIVE
+        self._prev = _SINKS_ACTIVE
+        _SINKS_ACTIVE = True
+        _SINK_SYNC_QUEUED.clear()
+        return self
+
+    def __exit__(self, *exc):
+        global _SINKS_ACTIVE
+        _SINKS_ACTIVE = self._prev
+        _SINK_SYNC_QUEUED.clear()
+        return False
+
+
 def _sinks_for(params):
-    if not _SINKS_ON or not _GRAD_SINKS:
+    if not _SINKS_ON or not _SINKS_ACTIVE or not _GRAD_SINKS:
         return None
     out = []
     for p in params:
@@ -231,7 +273,7 @@ def pack_params(spec: ModelSpec, tensors: dict) -> torch.Tensor:
     if n == 0:
         _lib.check(1, "snerf_packed_floats")
     dev = tensors[spec.param_names()[0]].device
-    packed = torch.empty(n, dtype=torch.float32, device=dev)
+    packed = _empty(n, dtype=torch.float32, device=dev)
     ps = params_struct(spec, tensors)
     with torch.cuda.device(dev):
         _lib.check(L.snerf_pack_params(C.byref(d), C.byref(ps), _ptr(packed), _stream()), "snerf_pack_params")
@@ -243,7 +285,7 @@ def unpack_grads(spec: ModelSpec, packed_grads: torch.Tensor, like: dict, accumu
     L = _lib.lib()
     d = spec.desc(1, 1)
     if accumulate_into is None:
-        grads = {n: torch.empty_like(like[n]) for n in spec.param_names()}
+        grads = {n: _empty_like(like[n]) for n in spec.param_names()}
     else:
         grads = accumulate_into
     ps = params_struct(spec, grads)
@@ -319,11 +361,11 @@ class _RenderPass(torch.autograd.Function):
         nbytes = L.snerf_workspace_bytes(C.byref(d))
         if nbytes == 0:
             _lib.check(1, "snerf_workspace_bytes")
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ws = _empty(nbytes, dtype=torch.uint8, device=dev)
         keys = output_keys(spec, sc_pass)
-        outs = {k: torch.empty(_OUT_SHAPES[k](N, S, spec.n_classes), dtype=torch.float32, device=dev) for k in keys}
-        label = torch.empty((N,), dtype=torch.int64, device=dev) if (spec.n_classes > 0 and not sc_pass) else None
-        z_out = torch.empty((N, S), dtype=torch.float32, device=dev)
+        outs = {k: _empty(_OUT_SHAPES[k](N, S, spec.n_classes), dtype=torch.float32, device=dev) for k in keys}
+        label = _empty((N,), dtype=torch.int64, device=dev) if (spec.n_classes > 0 and not sc_pass) else None
+        z_out = _empty((N, S), dtype=torch.float32, device=dev)
         so = _lib.SnerfOutputs()
         for k, v in outs.items():
             setattr(so, k, v.data_ptr())
@@ -364,9 +406,9 @@ class _RenderPass(torch.autograd.Function):
         if not live:
             return (None,) * (8 + len(ctx.names))
         dev = ctx.tc.device
-        pg = torch.zeros_like(ctx.packed)
-        d_t = torch.empty_like(ctx.tc)
-        d_ts = torch.empty_like(ctx.tsc) if ctx.tsc is not None else None
+        pg = torch.zeros(int(L.snerf_grad_floats(C.byref(d))), dtype=torch.float32, device=dev)   # the fp32 region only: the backward touches nothing else
+        d_t = _empty_like(ctx.tc)
+        d_ts = _empty_like(ctx.tsc) if ctx.tsc is not None else None
         si = ctx.pin.struct(ctx.tc, ctx.tsc)
         with torch.cuda.device(dev):
             _lib.check(L.snerf_backward(C.byref(d), _ptr(ctx.packed), C.byref(si), C.byref(go), _ptr(pg), _ptr(d_t),
@@ -434,7 +476,7 @@ def render_pass_into(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Te
     if nbytes == 0:
         _lib.check(1, "snerf_workspace_bytes")
     if workspace is None or workspace.numel() < nbytes or workspace.device != dev:
-        workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        workspace = _empty(nbytes, dtype=torch.uint8, device=dev)
     allowed = set(output_keys(spec, sc_pass)) | {"z_vals"} | ({"semantic_label"} if spec.n_classes > 0 and not sc_pass else set())
     so = _lib.SnerfOutputs()
     for k, v in out.items():

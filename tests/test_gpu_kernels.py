@@ -132,14 +132,25 @@ def _hip_render(cfg, gp, emb_g, b, dev, emb_s_g=None):
     return out
 
 
+LABEL_STATS = []   # one record per comparison: how many rays qualified for the exact-label check, disagreements among the rest
+
+
 def _compare_outputs(hip, ora, cfg):
     for k, v in ora.items():
         if k == "semantic_label_coarse":
+            # "class argmax bit-exact": the labels must agree wherever the oracle's top-2 margin exceeds twice the MEASURED error
+            # of the logits (a smaller margin is a tie inside fp32 noise of either implementation); nearly every ray qualifies,
+            # and the disagreements among the few that do not are counted and reported, not hidden
             logits = ora["semantic_logits_coarse"].detach()
+            lerr = max_abs(hip["semantic_logits_coarse"].detach().cpu(), logits)
             top2 = logits.topk(2, dim=-1).values
-            sure = (top2[:, 0] - top2[:, 1]) > 2 * OUT_TOL
-            assert torch.equal(hip[k].cpu()[sure], v[sure]), "class argmax differs on rays with a clear margin"
-            assert sure.float().mean() > 0.5
+            sure = (top2[:, 0] - top2[:, 1]) > 2 * max(lerr, 1e-6)
+            same = hip[k].cpu() == v
+            assert bool(same[sure].all()), "class argmax differs on rays with a clear margin"
+            frac = float(sure.float().mean())
+            assert frac >= 0.99 or sure.numel() < 200, ("margin-qualified fraction", frac)
+            LABEL_STATS.append({"rays": int(sure.numel()), "qualified": frac, "logit_err": lerr, "ambiguous": int((~sure).sum()),
+                                "ambiguous_disagree": int((~same[~sure]).sum())})
             continue
         err = max_abs(hip[k].detach().cpu(), v.detach())
         assert err <= OUT_TOL, (k, err)
@@ -351,3 +362,54 @@ def test_fp32_mfma_flag_path(monkeypatch):
         assert rel_err(outs["x6"][1][k].cpu(), outs["fp32"][1][k].cpu()) <= 1e-4 or \
             max_abs(outs["x6"][1][k].cpu(), outs["fp32"][1][k].cpu()) <= 1e-8, k
     assert max_abs(outs["x6"][0]["rgb_coarse"].detach().cpu(), outs["fp32"][0]["rgb_coarse"].detach().cpu()) <= 2e-6
+
+
+def test_forward_backward_capture_in_a_hip_graph():
+    """include/snerf_hip.h promises hot calls that allocate nothing, never synchronise and read no environment: one pass
+    (pack -> forward -> backward -> unpack, through ops.render_pass and autograd) is captured in a torch.cuda.CUDAGraph
+    (hipStreamBeginCapture underneath), replayed twice, and must reproduce the eager call's outputs and gradients bit for bit."""
+    from snerf_amd import ops
+    dev = _dev()
+    cfg = O.OracleCfg(fc_units=64, n_samples=16)
+    pn = O.init_params_numpy(cfg, 3)
+    b = O.batch_to_torch(O.synthetic_batch(256, 16, seed=5))
+    emb = torch.from_numpy(O.init_embedding_numpy(cfg, 3)).to(dev)
+    bg = {k: v.to(dev) for k, v in b.items()}
+
+    from snerf_amd import ops
+    spec = _spec(cfg)
+    rays, extras, u = bg["rays"], bg["extras"], bg["u"]
+    t = emb[extras[:, 3].long()]
+    zs = torch.linspace(0, 1, cfg.n_samples).to(dev)
+
+    def run(gp):       # device-resident inputs only: nothing below may copy from the host or synchronise
+        for p in gp.values():
+            p.grad = None
+        packed = ops.pack_params(spec, gp)
+        res = ops.render_pass(spec, gp, ops.PassInputs(sun_d=extras[:, :3], rays=rays, z_steps=zs, u=u), t, None, packed=packed)
+        sc = ops.render_pass(spec, gp, ops.PassInputs(sun_d=extras[:, :3], rays=rays, z_vals=res["z_vals"]), t, None, sc_pass=True, packed=packed)
+        loss = res["rgb"].square().sum() + res["depth"].sum() + res["semantic_logits"].sum() + sc["sun"].sum()
+        loss.backward()
+        outs = {k: v.detach().clone() for k, v in res.items() if v.is_floating_point()}
+        outs["sun_sc"] = sc["sun"].detach().clone()
+        return outs, {k: p.grad.clone() for k, p in gp.items() if p.grad is not None}
+
+    gp = _gpu_params(pn, dev, requires_grad=True)
+    out_e, grad_e = run(gp)                       # eager reference (also warms every lazy initialisation up)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                 # a warm-up on the capture stream, as torch asks for
+        run(gp)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_g, grad_g = run(gp)
+    for _ in range(3):   # later replays too: memset nodes / large by-value arguments once made them differ from the first (DESIGN.md)
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in out_e:
+            assert torch.equal(out_g[k], out_e[k]), (k, max_abs(out_g[k].cpu(), out_e[k].cpu()))
+        for k in grad_e:
+            assert torch.equal(grad_g[k], grad_e[k]), (k, max_abs(grad_g[k].cpu(), grad_e[k].cpu()))

@@ -5,6 +5,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.helpers import max_abs  # noqa: E402
+
 from oracle import snerf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -168,3 +170,60 @@ def test_trainloop_two_ranks_equal_one_rank(tmp_path, monkeypatch):
     for n, v in ref.items():
         assert torch.allclose(two["params"][n], v, rtol=0, atol=2e-5), (n, float((two["params"][n] - v).abs().max()))
     assert all(np.isfinite(two["losses"])) and all(np.isfinite(ref_losses))
+
+
+def _one_backward(loop, step=0, seed=321):
+    """the loss of one training step of the loop's pipeline (its own batch sampler, fixed jitter)"""
+    pl = loop.pipeline
+    pl.current_epoch = 0
+    batch = {"rgb": loop.bank.batch(step, loop.global_batch, loop.rank, loop.world, shuffle=loop.shuffle)}
+    torch.manual_seed(seed)
+    return pl.training_step(batch, step)["loss"]
+
+
+def test_gradient_sinks_equal_autograd_accumulation(monkeypatch):
+    """The passes may add their parameter gradients straight into FlatAdam's bucket (ops.accumulate_into_sinks, the training
+    loop's backward) instead of returning them to autograd: same seed, same step -> the flat gradient buffer is the same
+    to fp32 summation order, and bit-identical from run to run either way."""
+    from snerf_amd import ops
+    a, b = _loop(seed=9), _loop(seed=9)
+    for lp in (a, b):
+        lp.optimizer.zero_grad()
+    with ops.accumulate_into_sinks():
+        _one_backward(a).backward()
+    ops.wait_grad_sinks()
+    monkeypatch.setattr(ops, "_SINKS_ON", False)
+    _one_backward(b).backward()
+    torch.cuda.synchronize()
+    ga, gb = a.optimizer.flat_g.clone(), b.optimizer.flat_g.clone()
+    assert float(ga.abs().max()) > 0
+    assert max_abs(ga.cpu(), gb.cpu()) <= 1e-6 * float(gb.abs().max())
+    monkeypatch.setattr(ops, "_SINKS_ON", True)
+    a.optimizer.zero_grad()
+    with ops.accumulate_into_sinks():
+        _one_backward(a).backward()
+    ops.wait_grad_sinks()
+    torch.cuda.synchronize()
+    assert torch.equal(a.optimizer.flat_g, ga), "sink path is not bit-reproducible"
+
+
+def test_autograd_grad_contract_with_flat_adam():
+    """Outside ops.accumulate_into_sinks the passes keep the autograd contract even when every .grad is a view of FlatAdam's
+    bucket: torch.autograd.grad returns the gradients and leaves .grad untouched; so does a plain backward() (which then
+    accumulates through AccumulateGrad as usual)."""
+    lp = _loop(seed=11)
+    lp.optimizer.zero_grad()
+    params = lp.params
+    before = lp.optimizer.flat_g.clone()
+    grads = torch.autograd.grad(_one_backward(lp), params, allow_unused=True)
+    torch.cuda.synchronize()
+    assert torch.equal(lp.optimizer.flat_g, before), "autograd.grad wrote into .grad"
+    got = [g for g in grads if g is not None]
+    assert len(got) >= len(params) - 2 and all(bool(torch.isfinite(g).all()) for g in got)
+    assert max(float(g.abs().max()) for g in got) > 0
+    # the same gradients arrive in .grad through a plain backward
+    _one_backward(lp).backward()
+    torch.cuda.synchronize()
+    for p, g in zip(params, grads):
+        if g is not None:
+            assert max_abs(p.grad.cpu(), g.cpu()) <= 1e-6 * max(1e-12, float(g.abs().max()))

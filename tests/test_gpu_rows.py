@@ -419,16 +419,18 @@ def test_heavy_tailed_gradients():
     assert float(t_g.grad.cpu()[mask].abs().max()) == 0.0
 
 
-def test_embedding_rows_forward_backward():
+@pytest.mark.parametrize("vocab", [50, 96])
+def test_embedding_rows_forward_backward(vocab):
     """ops.embed_rows == nn.Embedding (reference: models["t"](ts), semantic/components/rendering.py:35-46): rows bit-equal,
-    the table gradient equal to torch's scatter-add to fp32 summation order, and bit-identical from run to run."""
+    the table gradient equal to torch's scatter-add to fp32 summation order, and bit-identical from run to run.  vocab 96:
+    BASELINE configs[4] raises `t_embedding_vocab` to cover four scenes' images."""
     from snerf_amd import ops
     torch.manual_seed(7)
-    emb = torch.nn.Embedding(50, 4).to(DEV)
-    ref = torch.nn.Embedding(50, 4).to(DEV)
+    emb = torch.nn.Embedding(vocab, 4).to(DEV)
+    ref = torch.nn.Embedding(vocab, 4).to(DEV)
     ref.load_state_dict(emb.state_dict())
-    idx = torch.randint(0, 50, (4099,), device=DEV)
-    idx[:7] = 49
+    idx = torch.randint(0, vocab, (4099,), device=DEV)
+    idx[:7] = vocab - 1
     w = torch.randn(4099, 4, device=DEV)
     rows = ops.embed_rows(emb, idx)
     want = ref(idx)
@@ -442,3 +444,6 @@ def test_embedding_rows_forward_backward():
     assert torch.equal(emb.weight.grad, g1)
     # float indices as the extras column carries them (rays' image index), through the renderer's own conversion
     assert torch.equal(ops.embed_rows(emb, idx.float().long()), want)
+    # an index outside the table: torch raises; the kernel marks the row (NaN), it does not invent zeros
+    bad = ops.embed_rows(emb, torch.tensor([0, vocab, -1], device=DEV))
+    assert torch.equal(bad[0], want.new_tensor(emb.weight[0].tolist())) and bool(torch.isnan(bad[1:]).all())
