@@ -5,25 +5,25 @@ from ...framework.components.training_step import BaseTrainingStep
 
 
 def color_and_depth_losses(pipeline, batch, results):
-    rgbs = batch["rgb"]["rgbs"]
-    if pipeline.get_current_epoch() < pipeline.cfgs.pipeline.first_beta_epoch:
-        loss, loss_dict = pipeline.loss_without_beta(results, rgbs)
-        pipeline.log("train/beta_loss_activated", 0.0)
-    else:
-        loss, loss_dict = pipeline.loss(results, rgbs)
-        pipeline.log("train/beta_loss_activated", 1.0)
-    if pipeline.cfgs.pipeline.depth_enabled:
-        if pipeline.train_steps < pipeline.ds_drop:
-            tmp = pipeline({"rays": batch["depth"]["rays"], "extras": batch["depth"]["extras"]})
-            kp_depths = torch.flatten(batch["depth"]["depths"][:, 0])
-            kp_weights = 1.0 if pipeline.cfgs.pipeline.ds_noweights else torch.flatten(batch["depth"]["weights"])
-            loss_depth, loss_dict_depth = pipeline.depth_loss(tmp, kp_depths, kp_weights)
-            loss = loss + loss_depth
-            loss_dict.update(loss_dict_depth)
-            pipeline.log("train/depth_loss_activated", 1.0)
-        else:
-            pipeline.log("train/depth_loss_activated", 0.0)
-    return loss, loss_dict
+    """colour loss by epoch (SNerfLoss before `first_beta_epoch`, SatNerfLoss after) + the depth-supervision branch while
+    `train_steps < ds_drop`; the log keys and the gate order are the reference's (they are what its TensorBoard shows)."""
+    pc = pipeline.cfgs.pipeline
+    with_beta = pipeline.get_current_epoch() >= pc.first_beta_epoch
+    total, terms = (pipeline.loss if with_beta else pipeline.loss_without_beta)(results, batch["rgb"]["rgbs"])
+    pipeline.log("train/beta_loss_activated", 1.0 if with_beta else 0.0)
+    if not pc.depth_enabled:
+        return total, terms
+    depth_on = pipeline.train_steps < pipeline.ds_drop
+    pipeline.log("train/depth_loss_activated", 1.0 if depth_on else 0.0)
+    if depth_on:
+        d = batch["depth"]
+        rendered = pipeline({"rays": d["rays"], "extras": d["extras"]})      # a second full forward on the depth rays
+        targets = d["depths"][:, 0].reshape(-1)
+        ray_weights = 1.0 if pc.ds_noweights else d["weights"].reshape(-1)
+        depth_total, depth_terms = pipeline.depth_loss(rendered, targets, ray_weights)
+        total = total + depth_total
+        terms.update(depth_terms)
+    return total, terms
 
 
 class SatNeRFTrainingStep(BaseTrainingStep):

@@ -2,7 +2,7 @@
 // waits, raw barriers, fragment reads, accumulator rescaling.
 #pragma once
 #include "bsp.h"
-#include "gemm_common.h"
+#include "tiles.h"
 
 namespace snerf {
 namespace bsp {

@@ -17,7 +17,7 @@
 // beyond the operand) so ragged tiles need no exec-mask branches in the k-loop.
 // Epilogue: each wave transposes its 32-row accumulator blocks through a private LDS strip and then works
 // on whole rows, so bias/aux loads and the C (+cos) stores are 16-B per lane, 256 contiguous bytes per row.
-#include "gemm_common.h"
+#include "gemm_common.h"   // legacy/
 
 #include <vector>
 
@@ -212,31 +212,12 @@ __global__ __launch_bounds__(NT, 3) void gemm_kernel(const KArgs p) {
 #endif
 }
 
-// ---- optional per-launch timing (snerf_profile_begin/_end): HIP events on the launch stream ----------
-struct ProfRec { hipEvent_t a, b; double flops; int variant; };
-static bool g_prof_on = false;
-static std::vector<ProfRec> g_prof;
-static std::vector<hipEvent_t> g_prof_pool;
-static size_t g_prof_used = 0;
-
-static hipEvent_t prof_event() {
-  if (g_prof_used == g_prof_pool.size()) {
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
-    g_prof_pool.push_back(e);
-  }
-  return g_prof_pool[g_prof_used++];
-}
+int prof_hook_begin(double flops, int variant, hipStream_t st);   // profile.hip
+void prof_hook_end(int token, hipStream_t st);
 
 template <int BI, int BJ, int WI, int WJ, bool A_IC, bool B_IC>
 static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
-  ProfRec rec{nullptr, nullptr, 0.0, 3};
-  if (g_prof_on) {
-    rec.a = prof_event(); rec.b = prof_event();
-    rec.flops = 2.0 * (double)g.I * (double)g.J * (double)g.K;
-    if (BI == 128 && BJ == 128) rec.variant = A_IC ? 2 : (B_IC ? 1 : 0);
-    if (rec.a && rec.b) (void)hipEventRecord(rec.a, stream);
-  }
+  const int tok = prof_hook_begin(2.0 * (double)g.I * (double)g.J * (double)g.K, (BI == 128 && BJ == 128) ? (A_IC ? 2 : (B_IC ? 1 : 0)) : 3, stream);
   KArgs p;
   p.A = g.A; p.A2 = g.A2 ? g.A2 : g.A; p.B = g.B; p.C = g.C; p.C2 = g.C2;
   p.bias = g.bias; p.aux = g.aux; p.colsum = g.colsum;
@@ -274,49 +255,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t stream) {
   }
   else hipLaunchKernelGGL((gemm_kernel<BI, BJ, WI, WJ, A_IC, B_IC>), grid, dim3(NT), 0, stream, p);
   SNERF_LAUNCH_CHECK();
-  if (g_prof_on && rec.a && rec.b) {
-    (void)hipEventRecord(rec.b, stream);
-    g_prof.push_back(rec);
-  }
-  return SNERF_OK;
-}
-
-// the same per-launch bracket for the launchers of bsp_gemm.hip
-namespace bsp {
-int prof_hook_begin(double flops, int variant, hipStream_t st) {
-  if (!g_prof_on) return -1;
-  ProfRec rec{prof_event(), prof_event(), flops, variant};
-  if (!rec.a || !rec.b) return -1;
-  (void)hipEventRecord(rec.a, st);
-  g_prof.push_back(rec);
-  return (int)g_prof.size() - 1;
-}
-void prof_hook_end(int token, hipStream_t st) {
-  if (token >= 0) (void)hipEventRecord(g_prof[token].b, st);
-}
-}  // namespace bsp
-
-int profile_begin() {
-  g_prof.clear();
-  g_prof_used = 0;
-  g_prof_on = true;
-  return SNERF_OK;
-}
-
-int profile_end(SnerfProfile* out) {
-  g_prof_on = false;
-  if (!out) { set_error("snerf_profile_end: null output"); return SNERF_ERR_NULL; }
-  for (int v = 0; v < SNERF_PROFILE_VARIANTS; ++v) { out->ms[v] = 0.0; out->flops[v] = 0.0; out->launches[v] = 0; }
-  for (const ProfRec& r : g_prof) {
-    SNERF_HIP_CHECK(hipEventSynchronize(r.b));
-    float ms = 0.f;
-    SNERF_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
-    out->ms[r.variant] += ms;
-    out->flops[r.variant] += r.flops;
-    out->launches[r.variant] += 1;
-  }
-  g_prof.clear();
-  g_prof_used = 0;
+  prof_hook_end(tok, stream);
   return SNERF_OK;
 }
 

@@ -1,8 +1,9 @@
 // Pieces shared by the fp32-MFMA GEMM (gemm.hip) and the split-bf16 GEMM (gemm_x6.hip):
 // kernel arguments, buffer-descriptor helpers, workgroup->tile map and the fused epilogue.
 #pragma once
-#include "gemm.h"
-#include "../../include/snerf_hip.h"
+#include "../gemm.h"
+#include "../tiles.h"
+#include "../../../include/snerf_hip.h"
 
 namespace snerf {
 
@@ -45,37 +46,6 @@ __device__ __forceinline__ size_t uniform_sz(size_t v) {
 // |cos| from the stored sine: hardware square root (1 ulp) of the once-rounded 1 - h^2; sqrtf() would expand into the
 // ~15-instruction correctly rounded sequence, four times per lane and pass
 __device__ __forceinline__ float cos_from_sin(float h) { return __builtin_amdgcn_sqrtf(fmaxf(fmaf(-h, h, 1.f), 0.f)); }
-
-// Workgroup -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), and the J-tiles of
-// one I-tile re-read the same A rows, so give each XCD group runs of consecutive J-tiles of the
-// same I-tile: those re-reads then hit that XCD's L2 instead of HBM. Speed only, never correctness.
-__device__ __forceinline__ void tile_of_block(int b, int tiles_i, int tiles_j, int& ti, int& tj) {
-  const int n = tiles_i * tiles_j;
-  const int xcd = b & 7, q = b >> 3;
-  const int per = n >> 3;  // tiles per XCD group (exact part)
-  if (b < (per << 3)) {
-    const int lin = xcd * per + q;  // contiguous chunk of the (ti-major) tile order per XCD group
-    ti = lin / tiles_j;
-    tj = lin - ti * tiles_j;
-  } else {  // remainder tiles (n % 8): identity order
-    ti = b / tiles_j;
-    tj = b - ti * tiles_j;
-  }
-}
-
-// Split-K launches (dW): grid = (tiles, 1, splits), dispatched x-fastest, so block f = x + tiles*z lands on XCD f % 8.
-// All tiles of one split read the same rows of dZ and X; remap so that one XCD group runs ALL tiles of a split
-// back to back (each operand block is then fetched from HBM once per split and shared through that L2).
-__device__ __forceinline__ void split_tile_of_block(int x, int z, int tiles, int splits, int& tile, int& split) {
-  const int s8 = splits & ~7;
-  tile = x; split = z;
-  if (z < s8) {
-    const int f = x + tiles * z;
-    const int xcd = f & 7, idx = f >> 3;
-    split = (idx / tiles) * 8 + xcd;
-    tile = idx - (idx / tiles) * tiles;
-  }
-}
 
 // thread -> (row, k) of its r-th float4 in a BI x BK k-tile (element e = t + NT*r of BI*BK/4).
 // KC: BK/4 lanes cover one row's BK floats; IC: BI/4 lanes cover one k-row.

@@ -68,6 +68,38 @@ def test_host_only_sizes_and_errors():
     assert L.snerf_version() == 2
 
 
+def test_plan_builder_over_model_variants_and_null_arguments():
+    """The host code behind the C-ABI (plan / table builders, argument checks) over every model variant, pass kind and
+    arithmetic; null and misaligned arguments of the hot calls come back as error codes with a message, never as a crash.
+    `make -C snerf_amd/csrc asan-test` runs this file against the ASAN + UBSAN host build of the library."""
+    from snerf_amd import _lib
+    from snerf_amd.ops import ModelSpec
+    L = _lib.lib()
+    seen = set()
+    for kw in ({}, {"siren": False}, {"model": "satnerf"} if "model" in ModelSpec.__dataclass_fields__ else {},
+               {"use_separate_beta_for_s": True}, {"use_tj_for_s": True}, {"use_tj_instead_of_beta": True}, {"fc_units": 64}, {"fc_units": 128, "fc_layers": 4, "fc_skips": (2,)}):
+        try:
+            spec = ModelSpec(**kw)
+        except TypeError:
+            continue
+        for flags in (0, _lib.FLAG_TRAIN, _lib.FLAG_SC_PASS, _lib.FLAG_TRAIN | _lib.FLAG_SC_PASS, _lib.FLAG_TRAIN | _lib.FLAG_SPLIT3, _lib.FLAG_BF16):
+            for N, S in ((1, 1), (77, 7), (4096, 64), (2048, 130)):
+                d = spec.desc(N, S, flags)
+                n, g, w = L.snerf_packed_floats(C.byref(d)), L.snerf_grad_floats(C.byref(d)), L.snerf_workspace_bytes(C.byref(d))
+                assert n > 0 and w > 0 and 0 < g <= n, (kw, flags, N, S, L.snerf_last_error())
+                seen.add((n, g))
+    assert len(seen) >= 4
+    d = ModelSpec().desc(64, 8, _lib.FLAG_TRAIN)
+    # hot calls with null / misaligned arguments: an error code and a message (no device work is reached)
+    assert L.snerf_pack_params(C.byref(d), None, None, None) != 0 and L.snerf_last_error()
+    assert L.snerf_forward(C.byref(d), None, None, None, None, 0, None) != 0
+    assert L.snerf_backward(C.byref(d), None, None, None, None, None, None, None, 0, None) != 0
+    assert L.snerf_unpack_grads(C.byref(d), None, None, 0, None) != 0
+    assert L.snerf_grad_floats(None) == 0 and L.snerf_workspace_bytes(None) == 0
+    bad = ModelSpec().desc(-5, 64)
+    assert L.snerf_grad_floats(C.byref(bad)) == 0 and L.snerf_workspace_bytes(C.byref(bad)) == 0
+
+
 def test_product_path_refuses_cpu_tensors():
     """No CPU fallback: the HIP path raises instead of computing on the host."""
     import torch

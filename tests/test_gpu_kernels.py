@@ -24,8 +24,9 @@ def _dev():
 
 
 # ----------------------------------------------------------------------------------------------------
-# the tiled fp32 MFMA GEMM in isolation
+# the round-1 GEMMs (csrc/legacy/) in isolation: fp32 MFMA and split-bf16 planes -- behind the arithmetic flags, not the default
 # ----------------------------------------------------------------------------------------------------
+@pytest.mark.legacy_arithmetic
 @pytest.mark.parametrize("a_ic,b_ic,narrow,I,J,K", [
     (0, 0, 0, 128, 128, 32), (0, 0, 0, 256, 512, 512), (0, 0, 0, 200, 100, 60), (0, 0, 0, 1000, 520, 572),
     (0, 0, 1, 384, 32, 768), (0, 0, 1, 77, 32, 16),
@@ -36,6 +37,7 @@ def test_gemm_layouts(a_ic, b_ic, narrow, I, J, K):
     _gemm_case(a_ic, b_ic, narrow, I, J, K)
 
 
+@pytest.mark.legacy_arithmetic
 @pytest.mark.parametrize("a_ic,b_ic,I,J,K", [
     (0, 0, 128, 128, 16), (0, 0, 256, 512, 512), (0, 0, 200, 100, 60), (0, 0, 1000, 520, 576), (0, 0, 77, 36, 1024),
     (1, 1, 128, 128, 32), (1, 1, 512, 512, 1024), (1, 1, 256, 60, 777), (1, 1, 1024, 524, 64), (1, 1, 36, 300, 5000),
@@ -45,6 +47,7 @@ def test_gemm_split_bf16(a_ic, b_ic, I, J, K):
     _gemm_case(a_ic, b_ic, 4, I, J, K)
 
 
+@pytest.mark.legacy_arithmetic
 @pytest.mark.parametrize("a_ic,b_ic,I,J,K", [(0, 0, 300, 256, 144), (1, 1, 256, 200, 1000)])
 @pytest.mark.parametrize("mode,tol", [(8, 3e-2), (16, 2e-4)])
 def test_gemm_reduced_planes(a_ic, b_ic, I, J, K, mode, tol):
@@ -299,6 +302,7 @@ def test_ragged_and_multi_chunk_sizes():
         assert rel_err(emb_g.grad.cpu(), emb_o.grad) <= GRAD_REL_TOL
 
 
+@pytest.mark.legacy_arithmetic
 def test_reduced_precision_modes_full_width(monkeypatch):
     """REDUCED-precision modes at the headline width (sem_siren_full fixture): `split2` (two bf16 planes, torch's "high")
     stays inside the 1e-4 output bar with gradients ~1e-4 relative; `bf16` (one plane, precision = 16 / "medium") is

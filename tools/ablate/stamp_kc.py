@@ -9,7 +9,7 @@ d = raw[: 8 * 4096].reshape(4096, 8).copy()
 wg = raw[8 * 4096:].reshape(-1, 4)
 d = d[d[:, 0] != 0]
 d[:, 7] &= 0xFFFFFFFF
-names = ["start", "loop", "drain", "head", "epilogue", "waits_all", "waits_s2s3"]
+names = ["start", "loop", "drain", "head", "epilogue", "waits_all", "strip_flush"]
 print("tiles stamped:", len(d))
 for i, n in enumerate(names):
     c = d[:, i + 1]
