@@ -26,7 +26,9 @@ def sum_squared_error(image_pred, image_gt, valid_mask=None):
     if valid_mask is None:
         return torch.sum(diff * diff), torch.tensor(float(diff.numel()), device=diff.device)
     w, count = _weights(valid_mask, diff)
-    return torch.sum(w * diff * diff), count
+    # excluded elements contribute an exact zero even when they hold NaN / Inf (0 * NaN would poison the sum; the reference's
+    # boolean gather never reads them)
+    return torch.sum(torch.where(w > 0, w * diff * diff, torch.zeros_like(diff))), count
 
 
 def mse(image_pred, image_gt, valid_mask=None, reduction="mean"):

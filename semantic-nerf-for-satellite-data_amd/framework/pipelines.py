@@ -130,6 +130,7 @@ class TrainLoop:
         if "depth" in pl.datasets:
             batch["depth"] = pl.datasets["depth"].batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)
         self.optimizer.zero_grad()
+        pl.logged = {k: v for k, v in pl.logged.items() if not k.startswith("train/")}   # a step reports only what IT logged (no stale terms of dropped losses)
         out = pl.training_step(batch, step)
         with ops.accumulate_into_sinks():   # a plain accumulate-into-.grad backward: the passes may write the optimiser's bucket directly
             out["loss"].backward()
