@@ -389,8 +389,9 @@ def main():
             "frac": alg / peak,                              # ALGORITHMIC fraction: SURVEY 8(d) FLOPs / dense 16-bit MFMA peak
             "frac_mfma_issued": alg * mult / peak,           # matrix-pipe occupancy: `mult` 16-bit MFMA products per fp32 product
             "mfma_products_per_fp32_product": mult, "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": ("snerf::bsp::gemm_kc_kernel (128 x 256 tile; A = fp16 planes by LDS-DMA, W = fragment-ordered planes straight from L2; "
-                       "3 x v_mfma_f32_32x32x16_f16 per 32x32x16 block; epilogue writes planes + block exponents)" if mode == "f16x2" else
+            "kernel": ("snerf::bsp::gemm_kc_kernel (persistent workgroups, two per CU, 128 x 256 tiles drawn from per-XCD counters; activations = "
+                       "fp16 planes by LDS-DMA, W = fragment-ordered planes straight from L2 as the MFMA A operand; 3 x v_mfma_f32_32x32x16_f16 "
+                       "per 32x32x16 block; one-pass sine epilogue on the accumulators, planes + block exponents out through LDS strips)" if mode == "f16x2" else
                        ("snerf::gemm_x6_kernel<false,true,NP,128> (split-bf16 planes from fp32 storage)" if x6 else
                         "snerf::gemm_kernel<128,128,64,64,false,false> (v_mfma_f32_32x32x2_f32)")),
             "vs_fp32_mfma_peak": alg / FP32_MFMA_PEAK_TFLOPS,

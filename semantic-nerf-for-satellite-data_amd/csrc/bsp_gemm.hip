@@ -112,7 +112,7 @@ template <int TI> struct DwCfg {
   static constexpr int NTH = TI == 256 ? 512 : 256, WAVES = NTH / 64;
   static constexpr int MI = TI == 256 ? 4 : 1;                   // 32-row blocks per wave along i
   static constexpr int A_PITCH = TI * 4;                         // bytes of one point row of the A stage (TI columns, both planes)
-  static constexpr int A_BYTES = 16 * A_PITCH, B_BYTES = 16 * 1024, STAGE = A_BYTES + B_BYTES, RING = 3;
+  static constexpr int A_BYTES = 16 * A_PITCH, B_BYTES = 16 * 1024, STAGE = A_BYTES + B_BYTES, RING = 3;   // stages in the ring, RING - 1 in flight (four: measured equal, 326 vs 327 us)
   static constexpr int STRIPS = WAVES * KC_STRIP;
   static constexpr int TAIL = (RING * STAGE > STRIPS) ? RING * STAGE : STRIPS;
   static constexpr int MAXCH = 128;                              // 128-point chunks per split (k_split <= 16384)
@@ -197,6 +197,8 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
 
   issue(0, 0);
   issue(1, 1);
+#pragma unroll
+  for (int r = 2; r < T::RING - 1; ++r) issue(r, r);
 
   f32x16 acc[T::MI][2];
 #pragma unroll
@@ -246,53 +248,40 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
       e_cur = e_new;
     }
   };
-#ifndef BSP_DW_LOCKSTEP
   if constexpr (TI == 256) {
     // Ping-pong: the eight waves form two groups (tile rows 0-127 / 128-255; one wave of each per SIMD) that run the same
     // two-phase step -- M: request stage s + 2, read the 24 fragments of stage s | C: 24 MFMAs on those registers -- one
     // phase apart, with a workgroup barrier after every phase.  While one wave of a SIMD issues its MFMAs back to back the
     // other does its LDS reads and DMA issue; in lockstep (all eight waves request, read, compute together) the three
-    // costs add up: measured 336 us lockstep / 311 us ping-pong at 262,144 x 512 x 512 (-DBSP_DW_LOCKSTEP builds the former).
+    // costs add up: measured 336 us lockstep / 311 us ping-pong at 262,144 x 512 x 512 (round 2; three-stage ring).
     //   phase:    0      1      2      3     ...
     //   group 0:  M(0)   C(0)   M(1)   C(1)
     //   group 1:  -      M(0)   C(0)   M(1)
     // Stage s + 1 is awaited (own pieces, counted vmcnt) before the barrier that ends phase 2 s + 1, one barrier ahead of
     // its first reader (group 0, phase 2 s + 2); stage s + 2 is requested into the slot of stage s - 1 no earlier than
-    // phase 2 s, one barrier after its last reader (group 1, phase 2 s - 1).
+    // phase 2 s, one barrier after its last reader (group 1, phase 2 s - 1).  A request has two to three phases (~0.6 us
+    // each at the headline shape) to land; a ring of four (four to five phases) measured the same: the kernel is bound by
+    // the rate at which a CU's L1 fills (2.1 GB per launch through the L1s at 25 GB/s per CU), not by the latency of a fill.
     const int grp = wave >> 2;
     f16x8 fa_h[4], fa_l[4], fb_h[2], fb_l[2];
     auto phaseM = [&](int s, int slot) {
-#ifndef BSP_ABL_DW_NODMA
-      issue(s + 2, (slot + 2) % 3);
-#endif
+      issue(s + T::RING - 1, (slot + T::RING - 1) % T::RING);
       chunk(s);
       const char* st = lds + slot * T::STAGE;
-#ifdef BSP_ABL_DW_NOLDSREAD
-      const f16x8 cst = __builtin_bit_cast(f16x8, u32x4{(unsigned)s, 1u, 2u, (unsigned)(size_t)st});
-#pragma unroll
-      for (int nj = 0; nj < 2; ++nj) { fb_h[nj] = cst; fb_l[nj] = cst; }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) { fa_h[mi] = cst; fa_l[mi] = cst; }
-#else
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) { fb_h[nj] = trfrag(st, foB[nj][0], 1024); fb_l[nj] = trfrag(st, foB[nj][1], 1024); }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) { fa_h[mi] = trfrag(st, foA[mi][0], PA); fa_l[mi] = trfrag(st, foA[mi][1], PA); }
-#endif
     };
     auto phaseC = [&]() {
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
-#ifdef BSP_ABL_DW_NOMFMA
-        asm volatile("" ::"v"(fa_h[mi]), "v"(fa_l[mi]), "v"(fb_h[0]), "v"(fb_l[0]), "v"(fb_h[1]), "v"(fb_l[1]));
-#else
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = mfma3(fa_h[mi], fa_l[mi], fb_h[nj], fb_l[nj], acc[mi][nj]);
-#endif
       __builtin_amdgcn_s_setprio(0);
     };
-    wait_vm<NPIECE>();          // stage 0 (own pieces); stage 1 stays in flight
+    wait_vm<(T::RING - 2) * NPIECE>();      // stage 0 (own pieces); the later ones stay in flight
     barrier_raw();
     if (grp == 0) {
       int slot = 0;
@@ -300,9 +289,9 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
         phaseM(s, slot);
         barrier_raw();
         phaseC();
-        wait_vm<NPIECE>();      // stage s + 1 landed (stage s + 2 in flight)
+        wait_vm<(T::RING - 2) * NPIECE>();  // stage s + 1 landed (stage s + 2 in flight)
         barrier_raw();
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot == T::RING - 1 ? 0 : slot + 1;
       }
       barrier_raw();            // group 1's last compute phase
     } else {
@@ -310,46 +299,29 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
       int slot = 0;
       for (int s = 0; s < nks; ++s) {
         phaseM(s, slot);
-        wait_vm<NPIECE>();      // stage s + 1 landed (the stage s + 2 just requested stays in flight)
+        wait_vm<(T::RING - 2) * NPIECE>();  // stage s + 1 landed (the stage s + 2 just requested stays in flight)
         barrier_raw();
         phaseC();
         barrier_raw();
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = slot == T::RING - 1 ? 0 : slot + 1;
       }
     }
   } else
-#endif
   {
   auto step = [&](int s, int slot) {
-#ifndef BSP_ABL_DW_NODMA
     wait_vm<NPIECE>();
-#endif
     barrier_raw();
-#ifndef BSP_ABL_DW_NODMA
-    issue(s + 2, (slot + 2) % 3);
-#endif
+    issue(s + T::RING - 1, (slot + T::RING - 1) % T::RING);
     chunk(s);
     const char* st = lds + slot * T::STAGE;
     f16x8 bh[2], bl[2];
-#ifdef BSP_ABL_DW_NOLDSREAD
-    bh[0] = bh[1] = bl[0] = bl[1] = __builtin_bit_cast(f16x8, u32x4{(unsigned)s, 1u, 2u, 3u});
-#else
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) { bh[nj] = trfrag(st, foB[nj][0], 1024); bl[nj] = trfrag(st, foB[nj][1], 1024); }
-#endif
 #pragma unroll
     for (int mi = 0; mi < T::MI; ++mi) {
-#ifdef BSP_ABL_DW_NOLDSREAD
-      const f16x8 ah = bh[0], al = bl[1];
-#else
       const f16x8 ah = trfrag(st, foA[mi][0], PA), al = trfrag(st, foA[mi][1], PA);
-#endif
-#ifdef BSP_ABL_DW_NOMFMA
-      asm volatile("" ::"v"(ah), "v"(al), "v"(bh[0]), "v"(bl[0]), "v"(bh[1]), "v"(bl[1]));
-#else
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = mfma3(ah, al, bh[nj], bl[nj], acc[mi][nj]);
-#endif
     }
   };
   for (int s = 0; s < nks; s += 3) {

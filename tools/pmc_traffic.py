@@ -61,4 +61,11 @@ for sub in ("iso_sq", "iso_sq2", "step_sq"):
         vals = {n: avg(v) for n, v in c.items()}
         print("  ", k[:44], {n: "%.4g" % v for n, v in vals.items()})
         out.setdefault(sub, {})[k] = vals
+try:
+    import subprocess
+    out["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or os.environ.get("SNERF_COMMIT")
+except Exception:
+    out["commit"] = os.environ.get("SNERF_COMMIT")
+out["provenance"] = ("tools/pmc_traffic.sh on one MI355X (gpurun box): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in passes of their own over "
+                     "`bench.py --steps 3 --warmup 2 --serial-passes` and over isolated launches; units calibrated on to_planes (known bytes)")
 json.dump(out, open(os.path.join(d, "pmc_hbm_traffic.json"), "w"), indent=1)
