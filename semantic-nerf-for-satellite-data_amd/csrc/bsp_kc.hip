@@ -25,7 +25,7 @@
 //            reference's own fp32 rounding of w0 z.
 //   others   (plain / ReLU forward, derivative epilogues of the backward pass) two passes: values + block |max| (two waves
 //            share a 128-column exponent block: one exchange through LDS), then split into planes and store.
-#include "bsp_dev.h"
+#include "bsp_kc_epi.h"
 
 namespace snerf {
 namespace bsp {
@@ -39,63 +39,6 @@ constexpr int KC_SMAX = KC_ETAB + 2 * 512;       // 4 floats: the waves' maxima
 constexpr int KC_HSIGN = KC_SMAX + 64;           // four 256-byte sign-word slots per wave
 constexpr int KC_NEXT = KC_HSIGN + 4 * 1024;     // index of the workgroup's next tile (written by wave 0)
 constexpr int KC_LDS = KC_NEXT + 64;
-constexpr float INV_PI = 0.31830988618379067154f;
-constexpr unsigned OOBH = 0x80000000u;           // rejected voffset that survives the addition of an instruction offset
-
-constexpr int SIN_POLY = 0, SIN_HW = 1;
-
-// sin(pi u_c) in place for eight values.  SIGNS: bit "cos(pi u_c) < 0" (= parity of round(u_c)) enters `sw` from the top,
-// earlier bits move down (after 32 calls' worth the first element sits in bit 0).
-template <bool SIGNS, int SINM>
-__device__ __forceinline__ void sinpi8(float (&u)[8], unsigned& sw) {
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    const float t = u[c] + 12582912.f;                 // low mantissa bits = k = round(u)
-    const unsigned tb = __float_as_uint(t);
-    float s;
-    if (SINM == SIN_HW) {
-      float fr;
-      asm("v_fract_f32 %0, %1" : "=v"(fr) : "v"(0.5f * u[c]));
-      asm("v_sin_f32 %0, %1" : "=v"(s) : "v"(fr));
-    } else {
-      const float kf = t - 12582912.f;
-      const float f = u[c] - kf;                       // exact, |f| <= 1/2
-      const float f2 = f * f;
-      float q = fmaf(f2, 0.077218386155008978f, -0.59804419391100816f);
-      q = fmaf(q, f2, 2.5500311935191413f);
-      q = fmaf(q, f2, -5.1677068661679284f);
-      q = fmaf(q, f2, 3.1415925798055815f);
-      s = __uint_as_float((tb << 31) + __float_as_uint(f * q));   // (-1)^k: one v_lshl_add
-    }
-    u[c] = s;
-    if (SIGNS) sw = __builtin_amdgcn_alignbit(tb, sw, 1);
-  }
-}
-
-// sum over the 32 lanes that share l >> 5 (DPP adds inside the 16-lane rows, row_bcast15 across the pair of rows); valid in
-// lanes 16-31 (l >> 5 == 0) and 48-63 (l >> 5 == 1)
-__device__ __forceinline__ float sum32(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));  // row_bcast15 -> rows 1, 3
-  return v;
-}
-
-// maximum over the wave of non-negative values (DPP inside the 16-lane rows, then the four rows through scalar registers:
-// no lane-index registers to keep alive as ds_bpermute shuffles need)
-__device__ __forceinline__ float wave_max(float v) {
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
-  const int b = __builtin_bit_cast(int, v);
-  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
-  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
-  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-
 // DIAG (tools/ablate/build_diag.sh only; the product instantiates DIAG = false): KcArgs::dbg removes operand traffic through
 // zero-size descriptors -- 1: A, 2: W (host side), 4: stores, 8: every tile reads the first 128 rows of A (always L2-resident).
 // Timing-only: the results are wrong.
@@ -601,6 +544,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 int prof_hook_begin(double flops, int variant, hipStream_t st);   // gemm.hip: per-launch HIP events when profiling is on
 void prof_hook_end(int token, hipStream_t st);
 int check_kc(const KcArgs& a, bool narrow);                        // bsp_gemm.hip
+int launch_kc8(KcArgs a, bool sin_hw, hipStream_t st);             // bsp_kc8.hip
 
 static int sin_mode() {   // SNERF_SIN=poly: the polynomial instead of v_sin_f32 (A/B; read once)
   static const int m = [] { const char* e = getenv("SNERF_SIN"); return (e && e[0] == 'p') ? SIN_POLY : SIN_HW; }();
@@ -619,11 +563,22 @@ static int kc_slots() {
   return n;
 }
 
+static bool kc_wide() {   // SNERF_KC=8: the 256 x 256 kernel of bsp_kc8.hip (A/B; read once)
+  static const bool w = [] { const char* e = getenv("SNERF_KC"); return e && e[0] == '8'; }();
+  return w;
+}
+static bool cs_bias_check(const KcArgs& a) {
+  if (a.colsum != nullptr && a.bias != nullptr) { set_error("bsp gemm: bias and column sums in one launch"); return true; }
+  return false;
+}
+
 int launch_kc(const KcArgs& a0, hipStream_t st) {
   KcArgs a = a0;
   if (!a.A2) { a.A2 = a.A; a.EA2 = a.EA; a.lda2 = a.lda; a.a2_col0 = a.a_col0; if (a.Ka == 0) a.Ka = a.K; }
   int rc = check_kc(a, false);
   if (rc) return rc;
+  if (cs_bias_check(a)) return SNERF_ERR_BAD_DESC;
+  if (kc_wide()) return launch_kc8(a, sin_mode() == SIN_HW, st);
   a.tiles_i = (a.I + 127) / 128;
   a.tiles_j = (a.J + 255) / 256;
 #ifdef KC_DIAG_BUILD
@@ -638,7 +593,6 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   const dim3 grid(ntiles < slots ? ntiles : slots), block(256);   // persistent workgroups, two per CU; tile = block + n * grid
   const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.K, 0, st);
   const bool cs = a.colsum != nullptr;
-  if (cs && a.bias != nullptr) { set_error("bsp gemm: bias and column sums in one launch"); return SNERF_ERR_BAD_DESC; }
 #define KC_LAUNCH(ACT_, AUX_, CS_, SG_, SM_) hipLaunchKernelGGL((gemm_kc_kernel<ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a)
   if (a.aux_mode == AUX_SINREC) KC_LAUNCH(ACT_NONE, AUX_SINREC, true, false, SIN_POLY);
   else if (a.aux_mode == AUX_RELU_MASK) KC_LAUNCH(ACT_NONE, AUX_RELU_MASK, true, false, SIN_POLY);

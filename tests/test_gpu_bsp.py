@@ -221,3 +221,19 @@ def test_dw_column_offsets_and_narrow():
     assert _relerr(Cn, refn) <= max(2.0 * _relerr(An.T @ B, refn), 3e-7)
     Cn2 = _dw(An, B, 9, 200, b_col0=192, narrow=True)
     assert _relerr(Cn2, An[:, :9].double().T @ B[:, 192:392].double()) <= 6e-7
+
+
+@pytest.mark.parametrize("env", [{"SNERF_KC_GRID": "3"}, {"SNERF_KC": "8"}, {"SNERF_KC": "8", "SNERF_KC_GRID": "2"}],
+                         ids=["tile_loop_forced", "wide_256x256", "wide_tile_loop_forced"])
+def test_kc_variants_in_a_child_process(env):
+    """The library reads its switches once per process, so the K-contiguous cases above run again in a child process:
+    with a persistent grid of 3 / 2 workgroups (every workgroup walks several tiles and draws them from the counters even
+    at these small sizes) and on the 256 x 256 kernel of csrc/bsp_kc8.hip (SNERF_KC=8; same C-ABI, same results)."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_kc_ and not narrow and not child_process"], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
