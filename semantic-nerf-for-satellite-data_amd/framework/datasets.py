@@ -21,8 +21,15 @@ def shard_bounds(n: int, rank: int, world: int):
 
 
 class GpuRayBank:
-    def __init__(self, tensors: dict, n_classes: int = 5, car_cls_idx: int = 4, seed: int = 0, device=None):
+    def __init__(self, tensors: dict, n_classes: int = 5, car_cls_idx: int = 4, seed: int = 0, device=None, image_sizes=None):
+        """`image_sizes`: H*W of every image of a test bank, in row order (the reference's test DataLoader hands over one image
+        per step, framework/pipelines.py:120-129); without it `image()` cuts equal synthetic slices."""
         self.t = {k: (v.to(device) if device is not None else v) for k, v in tensors.items()}
+        self.image_sizes = [int(x) for x in image_sizes] if image_sizes is not None else None
+        if self.image_sizes is not None:
+            if sum(self.image_sizes) != int(self.t["rays"].shape[0]) or min(self.image_sizes) <= 0:
+                raise ValueError("image_sizes must be positive and sum to the number of rays in the bank")
+            self._image_lo = np.concatenate([[0], np.cumsum(self.image_sizes)]).astype(np.int64)
         self.semantic_n_classes = n_classes
         self.car_cls_idx = car_cls_idx
         self.seed = seed
@@ -67,16 +74,26 @@ class GpuRayBank:
             t["semantic_sparsity_mask"] = torch.ones(n_rays, dtype=torch.bool)
         return GpuRayBank(t, n_classes=n_classes, car_cls_idx=n_classes - 1, seed=seed, device=device)
 
-    def n_images(self, rays_per_image: int) -> int:
+    def n_images(self, rays_per_image: int = None) -> int:
+        if rays_per_image is None:
+            if self.image_sizes is None:
+                raise ValueError("this bank carries no image sizes: pass rays_per_image")
+            return len(self.image_sizes)
         return len(self) // rays_per_image
 
-    def image(self, i: int, rays_per_image: int, rank: int = 0, world: int = 1) -> dict:
-        """rows of validation "image" i (the reference's test DataLoader hands over one image's H*W rays per step,
-        framework/pipelines.py:120-129); under data parallelism each rank takes a contiguous slice of the image's rays
-        (ragged tails allowed: validation sums carry their counts)"""
-        lo, hi = i * rays_per_image, (i + 1) * rays_per_image
-        per = -(-rays_per_image // world)
+    def image(self, i: int, rays_per_image: int = None, rank: int = 0, world: int = 1) -> dict:
+        """rows of validation image i: the bank's own image i (`image_sizes`) when `rays_per_image` is None, else the i-th
+        slice of `rays_per_image` rows (synthetic banks).  Under data parallelism each rank takes a contiguous slice of the
+        image's rays (ragged tails allowed: validation sums carry their counts); an image with fewer rays than would give
+        every rank at least one is refused (a zero-size launch has no defined result)."""
+        if rays_per_image is None:
+            lo, hi = int(self._image_lo[i]), int(self._image_lo[i + 1])
+        else:
+            lo, hi = i * rays_per_image, (i + 1) * rays_per_image
+        per = -(-(hi - lo) // world)
         a, b = min(lo + rank * per, hi), min(lo + (rank + 1) * per, hi)
+        if (hi - lo) <= (world - 1) * per:
+            raise ValueError(f"validation image {i} has {hi - lo} rays: too few to give each of {world} ranks a slice")
         return {k: v[a:b] for k, v in self.t.items()}
 
     def steps_per_epoch(self, global_batch: int) -> int:

@@ -154,7 +154,10 @@ class TrainLoop:
         (eval/eval_semantic.py:63-77,122-140) -- one host read at the very end.  Ranks share each image's rays."""
         pl = self.pipeline
         bank = pl.datasets["rgb_test"]
-        hw = rays_per_image or min(len(bank), 64 * 64)
+        # images: the bank's own per-image ray counts where it carries them (real data: the reference's per-image means,
+        # framework/pipelines.py:120-129, eval_semantic.py:63-77); else equal slices of `rays_per_image` rows -- a SYNTHETIC
+        # definition of "image" (the means are then per-slice means)
+        hw = rays_per_image or (None if getattr(bank, "image_sizes", None) else min(len(bank), 64 * 64))
         n = bank.n_images(hw)
         if max_images is not None:
             n = min(n, max_images)

@@ -211,3 +211,24 @@ def test_siren_init_ranges():
     m = load_pipeline(cfgs).model_coarse
     w = m.fc_net[2].weight.detach()
     assert float(w.abs().max()) <= 1.0 / math.sqrt(w.shape[1]) + 1e-6
+
+
+def test_ray_bank_per_image_sizes():
+    """A test bank that carries each image's H*W hands over the reference's images (one per validation step,
+    framework/pipelines.py:120-129), whole or as contiguous rank slices; synthetic banks cut equal slices."""
+    from snerf_amd.framework.datasets import GpuRayBank
+    n = 20
+    t = {"rays": torch.arange(n, dtype=torch.float32)[:, None].repeat(1, 8), "extras": torch.zeros(n, 4)}
+    bank = GpuRayBank(t, image_sizes=[5, 9, 6])
+    assert bank.n_images() == 3
+    assert bank.image(1)["rays"][:, 0].tolist() == list(range(5, 14))
+    parts = [bank.image(1, None, r, 2)["rays"][:, 0].tolist() for r in range(2)]
+    assert parts[0] + parts[1] == list(range(5, 14)) and len(parts[0]) == 5
+    with pytest.raises(ValueError):
+        bank.image(0, None, 0, 8)                      # 5 rays cannot feed 8 ranks
+    with pytest.raises(ValueError):
+        GpuRayBank(t, image_sizes=[5, 9])              # does not cover the bank
+    plain = GpuRayBank(t)
+    assert plain.n_images(6) == 3 and plain.image(2, 6)["rays"][:, 0].tolist() == list(range(12, 18))
+    with pytest.raises(ValueError):
+        plain.n_images()
