@@ -25,7 +25,11 @@ namespace bsp {
 
 constexpr int RB = 128;          // rows per exponent block
 constexpr int CB = 128;          // columns per exponent block
-constexpr int E_MAX = 100;       // |exponent| clamp (2^e must be an fp32 normal; denormal maxima just lose bits)
+constexpr int E_MAX = 100;       // |exponent| clamp (2^e must be an fp32 normal)
+// Quiet side: a block whose |max| is below 2^-47 keeps exponent 60 and loses bits (it flushes to zero below ~2^-84).  Where the
+// exponent changes along a contraction the GEMMs rescale their fp32 accumulators by 2^(difference); with the quiet side
+// capped, a loud block (|max| up to ~1e8) next to a vanishing one moves them by at most 2^74 -- finite for K <= 2048.
+constexpr int E_QUIET = 60;
 
 typedef __amdgpu_buffer_rsrc_t srd_t;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -44,7 +48,7 @@ __host__ __device__ inline unsigned g16_off(int k) { return (unsigned)(k >> 4) *
 __host__ __device__ inline int exp_of_maxbits(unsigned b) {
   if (b == 0u || b >= 0x7f800000u) return 0;
   int e = 13 - ((int)(b >> 23) - 127);
-  return e < -E_MAX ? -E_MAX : (e > E_MAX ? E_MAX : e);
+  return e < -E_MAX ? -E_MAX : (e > E_QUIET ? E_QUIET : e);
 }
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }   // |e| <= 126
 

@@ -233,13 +233,18 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
   };
 
   int e_cur = 0;
+  bool quiet = false;     // the current chunk is dropped (below)
   constexpr int NPIECE = NPA + NPB;
-  // exponent bookkeeping at the start of a 128-point chunk: rescale the accumulators when the pair of exponents changes
+  // exponent bookkeeping at the start of a 128-point chunk: rescale the accumulators when the pair of exponents changes.
+  // The sum of two exponents can move by more than the accumulators can follow (2^41 x 2^de must stay finite): a chunk more
+  // than 2^64 quieter than the frame the accumulators are in adds nothing an fp32 sum could hold next to what is already
+  // there -- its weight fragments are zeroed and the frame stays (a lone quiet chunk no longer ends in Inf / NaN gradients).
   auto chunk = [&](int s) {
     if ((s & 7) != 0) return;
     const int e_new = __builtin_amdgcn_readfirstlane(esum[wave * T::MAXCH + (s >> 3)]);
+    quiet = s != 0 && e_new - e_cur > 64;
     if (s == 0) e_cur = e_new;
-    else if (__builtin_expect(e_new != e_cur, 0)) {
+    else if (__builtin_expect(e_new != e_cur && !quiet, 0)) {
       const int de = e_new - e_cur;
 #pragma unroll
       for (int mi = 0; mi < T::MI; ++mi)
@@ -272,6 +277,10 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
       for (int nj = 0; nj < 2; ++nj) { fb_h[nj] = trfrag(st, foB[nj][0], 1024); fb_l[nj] = trfrag(st, foB[nj][1], 1024); }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) { fa_h[mi] = trfrag(st, foA[mi][0], PA); fa_l[mi] = trfrag(st, foA[mi][1], PA); }
+      if (__builtin_expect(quiet, 0)) {
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) { fb_h[nj] = f16x8{}; fb_l[nj] = f16x8{}; }
+      }
     };
     auto phaseC = [&]() {
       __builtin_amdgcn_s_setprio(1);
@@ -317,6 +326,10 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
     f16x8 bh[2], bl[2];
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj) { bh[nj] = trfrag(st, foB[nj][0], 1024); bl[nj] = trfrag(st, foB[nj][1], 1024); }
+    if (__builtin_expect(quiet, 0)) {
+#pragma unroll
+      for (int nj = 0; nj < 2; ++nj) { bh[nj] = f16x8{}; bl[nj] = f16x8{}; }
+    }
 #pragma unroll
     for (int mi = 0; mi < T::MI; ++mi) {
       const f16x8 ah = trfrag(st, foA[mi][0], PA), al = trfrag(st, foA[mi][1], PA);

@@ -223,6 +223,43 @@ def test_dw_column_offsets_and_narrow():
     assert _relerr(Cn2, An[:, :9].double().T @ B[:, 192:392].double()) <= 6e-7
 
 
+def test_vanishing_blocks_next_to_loud_ones_stay_finite():
+    """Blocks 2^90 ... 2^110 apart along a contraction: the exponent of a vanishing block is capped at 60
+    (it loses bits, then flushes) and dW drops a chunk more than 2^64 below the frame of its accumulators, so the
+    accumulator rescale cannot overflow: finite results, within the yardstick of an fp32 GEMM, where a lone quiet block
+    used to end in Inf / NaN gradients."""
+    g = torch.Generator().manual_seed(11)
+    I, K, J = 300, 640, 256
+    A = torch.randn(I, K, generator=g)
+    A[:, 128:256] *= 2.0 ** -90      # nonzero, vanishing: between two ordinary blocks
+    A[:, 256:384] *= 2.0 ** 20       # loud
+    A[:, 384:512] *= 2.0 ** -110     # vanishing again, then an ordinary block ends the contraction
+    W = torch.randn(J, K, generator=g)
+    A, W = A.to(DEV), W.to(DEV)
+    Cm, _, _ = _kc(A, W)
+    ref = A.double() @ W.double().T
+    assert bool(torch.isfinite(Cm).all())
+    assert _relerr(Cm, ref) <= max(2.0 * _relerr(A @ W.T, ref), 3e-7)
+    # ends ON a vanishing block (the epilogue's frame is the quiet one)
+    Cq, _, _ = _kc(A[:, :512].contiguous(), W[:, :512].contiguous())
+    refq = A[:, :512].double() @ W[:, :512].double().T
+    assert bool(torch.isfinite(Cq).all()) and _relerr(Cq, refq) <= max(2.0 * _relerr(A[:, :512] @ W[:, :512].T, refq), 3e-7)
+    # dW: chunks of points 2^-100 / 2^-60 (both operands) between ordinary ones, first and last chunk included
+    P = 1536
+    X = torch.randn(P, 256, generator=g)
+    Z = torch.randn(P, 256, generator=g)
+    sc = torch.ones(P)
+    sc[:128] = 2.0 ** -100
+    sc[384:512] = 2.0 ** -60
+    sc[1408:] = 2.0 ** -100
+    Xs = (X * sc[:, None]).to(DEV)
+    Zs = (Z * sc[:, None]).to(DEV)     # products down to 2^-200: exponent sums far beyond the accumulators' reach
+    Cd = _dw(Zs, Xs, 256, 256, k_split=1536)
+    refd = Zs.double().T @ Xs.double()
+    assert bool(torch.isfinite(Cd).all())
+    assert _relerr(Cd, refd) <= max(2.0 * _relerr(Zs.T @ Xs, refd), 3e-7)
+
+
 @pytest.mark.parametrize("env", [{"SNERF_KC_GRID": "3"}, {"SNERF_KC": "8"}, {"SNERF_KC": "8", "SNERF_KC_GRID": "2"}],
                          ids=["tile_loop_forced", "wide_256x256", "wide_tile_loop_forced"])
 def test_kc_variants_in_a_child_process(env):
