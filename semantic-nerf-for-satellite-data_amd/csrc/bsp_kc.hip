@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   auto prepare = [&](int vb) {
     const kargs_t a = kargs();
     const int l = opaque(lane);
-    tile_of_block(vb, tiles_i, tiles_j, ti, tj);
+    tile_of_block(vb, tiles_i, tiles_j, ti, tj, a->rev != 0);
     i0 = ti * 128; j0 = tj * 256;
     const int lda = a->lda;
     const int i0a = (DIAG && (a->dbg & 8)) ? 0 : i0;

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kc8_kernel(const KcArgs) {
   auto prepare = [&](int vb) {
     const kargs_t a = kargs();
     const int l = opaque(lane);
-    tile_of_block(vb, tiles_i, tiles_j, ti, tj);
+    tile_of_block(vb, tiles_i, tiles_j, ti, tj, a->rev != 0);
     i0 = ti * 256; j0 = tj * 256;
     const int lda = a->lda;
     srdCur = make_srd(a->A + ((size_t)i0 * lda + a->a_col0) * 4, clamp_bytes(((unsigned long long)(a->I - i0 - 1) * lda + a->Ka) * 4ull));

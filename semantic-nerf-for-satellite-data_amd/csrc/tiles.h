@@ -7,12 +7,15 @@ namespace snerf {
 // Workgroup -> tile map: blocks b and b+8 share an XCD (round-robin dispatch), and the J-tiles of
 // one I-tile re-read the same A rows, so give each XCD group runs of consecutive J-tiles of the
 // same I-tile: those re-reads then hit that XCD's L2 instead of HBM. Speed only, never correctness.
-__device__ __forceinline__ void tile_of_block(int b, int tiles_i, int tiles_j, int& ti, int& tj) {
+// `rev`: every group walks its chunk backwards -- a launch that consumes the tensor the previous launch has just written
+// (layer n + 1 after layer n, dX of layer n after dX of layer n + 1) then starts with the rows written last, which the
+// memory-side cache (256 MB) still holds.
+__device__ __forceinline__ void tile_of_block(int b, int tiles_i, int tiles_j, int& ti, int& tj, bool rev = false) {
   const int n = tiles_i * tiles_j;
   const int xcd = b & 7, q = b >> 3;
   const int per = n >> 3;  // tiles per XCD group (exact part)
   if (b < (per << 3)) {
-    const int lin = xcd * per + q;  // contiguous chunk of the (ti-major) tile order per XCD group
+    const int lin = xcd * per + (rev ? per - 1 - q : q);  // contiguous chunk of the (ti-major) tile order per XCD group
     ti = lin / tiles_j;
     tj = lin - ti * tiles_j;
   } else {  // remainder tiles (n % 8): identity order
