@@ -112,6 +112,7 @@ struct KcArgs {
   const char* H = nullptr; const int* EH = nullptr; int ldh = 0; int h_col0 = 0; const unsigned* Hsign = nullptr;
   float* colsum = nullptr; int ldcs = 0;   // partial column sums of the stored values, one row per 128-row tile (bias gradients)
   int tiles_i = 0, tiles_j = 0;
+  int n_grp = 0;                     // bsp_kc9.hip: XCD groups of the launch (8 or 1)
   int rev = 0;                       // walk the tiles of every XCD group backwards (tiles.h)
   int dbg = 0;                       // diagnostic builds only (bsp_kc.hip: DIAG); ignored by the product kernels
   int* tile_ctr = nullptr;           // 8 zeroed ints (one 64-byte slot per launch): tiles beyond the first are drawn from them; null: fixed shares

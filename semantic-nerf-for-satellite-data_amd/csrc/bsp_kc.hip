@@ -545,6 +545,7 @@ int prof_hook_begin(double flops, int variant, hipStream_t st);   // gemm.hip: p
 void prof_hook_end(int token, hipStream_t st);
 int check_kc(const KcArgs& a, bool narrow);                        // bsp_gemm.hip
 int launch_kc8(KcArgs a, bool sin_hw, hipStream_t st);             // bsp_kc8.hip
+int launch_kc9(KcArgs a, bool sin_hw, hipStream_t st);             // bsp_kc9.hip (-1: does not qualify)
 
 static int sin_mode() {   // SNERF_SIN=poly: the polynomial instead of v_sin_f32 (A/B; read once)
   static const int m = [] { const char* e = getenv("SNERF_SIN"); return (e && e[0] == 'p') ? SIN_POLY : SIN_HW; }();
@@ -567,6 +568,10 @@ static bool kc_wide() {   // SNERF_KC=8: the 256 x 256 kernel of bsp_kc8.hip (A/
   static const bool w = [] { const char* e = getenv("SNERF_KC"); return e && e[0] == '8'; }();
   return w;
 }
+static bool kc_staggered() {   // SNERF_KC=9: SIREN forward launches on the staggered-halves kernel of bsp_kc9.hip (A/B; read once)
+  static const bool w = [] { const char* e = getenv("SNERF_KC"); return e && e[0] == '9'; }();
+  return w;
+}
 static bool cs_bias_check(const KcArgs& a) {
   if (a.colsum != nullptr && a.bias != nullptr) { set_error("bsp gemm: bias and column sums in one launch"); return true; }
   return false;
@@ -579,6 +584,7 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   if (rc) return rc;
   if (cs_bias_check(a)) return SNERF_ERR_BAD_DESC;
   if (kc_wide()) return launch_kc8(a, sin_mode() == SIN_HW, st);
+  if (kc_staggered()) { const int r9 = launch_kc9(a, sin_mode() == SIN_HW, st); if (r9 >= 0) return r9; }
   a.tiles_i = (a.I + 127) / 128;
   a.tiles_j = (a.J + 255) / 256;
 #ifdef KC_DIAG_BUILD

@@ -260,12 +260,14 @@ def test_vanishing_blocks_next_to_loud_ones_stay_finite():
     assert _relerr(Cd, refd) <= max(2.0 * _relerr(Zs.T @ Xs, refd), 3e-7)
 
 
-@pytest.mark.parametrize("env", [{"SNERF_KC_GRID": "3"}, {"SNERF_KC": "8"}, {"SNERF_KC": "8", "SNERF_KC_GRID": "2"}],
-                         ids=["tile_loop_forced", "wide_256x256", "wide_tile_loop_forced"])
+@pytest.mark.parametrize("env", [{"SNERF_KC_GRID": "3"}, {"SNERF_KC": "8"}, {"SNERF_KC": "8", "SNERF_KC_GRID": "2"},
+                                 {"SNERF_KC": "9"}, {"SNERF_KC": "9", "SNERF_KC_GRID": "2"}],
+                         ids=["tile_loop_forced", "wide_256x256", "wide_tile_loop_forced", "staggered_halves", "staggered_tile_loop_forced"])
 def test_kc_variants_in_a_child_process(env):
     """The library reads its switches once per process, so the K-contiguous cases above run again in a child process:
     with a persistent grid of 3 / 2 workgroups (every workgroup walks several tiles and draws them from the counters even
-    at these small sizes) and on the 256 x 256 kernel of csrc/bsp_kc8.hip (SNERF_KC=8; same C-ABI, same results)."""
+    at these small sizes), on the 256 x 256 kernel of csrc/bsp_kc8.hip (SNERF_KC=8) and with the SIREN forward launches on the
+    staggered-halves kernel of csrc/bsp_kc9.hip (SNERF_KC=9) -- same C-ABI, same results."""
     import os
     import subprocess
     import sys
