@@ -267,10 +267,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kc9_kernel(const KcArgs) {
         }
         advance();
       };
+      __builtin_amdgcn_s_setprio(2);   // MFMA issue goes before the other group's epilogue stream on the same SIMD
       for (int j = 0; j < nks; j += 2) {
         stage(j, w0, w1);
         if (j + 1 < nks) stage(j + 1, w1, w0);
       }
+      __builtin_amdgcn_s_setprio(0);
     }
     {
       // ---- epilogue: 16 stages, one chunk each.  Chunk c = half (gg) of the 32 x 32 block (mi, nj): u = acc * su + b, sine,
@@ -313,9 +315,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kc9_kernel(const KcArgs) {
         const int mi = c >> 2, nj = (c >> 1) & 1, gg = c & 1, gq = 2 * nj + gg;
         // before the barrier: the drawn tile index for the group's other waves (requested in chunk 0: home since the wait of chunk 3)
         if (c == 4 && wn == 0 && el == 0) { asm volatile("" : "+v"(drawn)); misc[g] = 2 * cls + drawn; }
-        if (c >= 2) wait_vm<12>(); else wait_vm<8>();   // one of the two stages before an epilogue stage c >= 2 issued 4 stores besides its 4 requests
+        // what the two stages before this one have issued (it may still be in flight): a chunk requests 2 weight pieces (+ 2 A pieces
+        // of the next tile from chunk 12 on) and, odd chunks, 4 stores; a k-loop stage 4 pieces
+        if (c == 0) wait_vm<8>(); else if (c == 1) wait_vm<6>(); else if (c <= 12) wait_vm<8>(); else if (c == 13) wait_vm<10>(); else wait_vm<12>();
         barrier_raw();
-        issueA((nks + c + 4 - P) & 3, have_nxt && nks + c + 4 - P >= 0 && nks + c + 4 - P < nks);
+        if (c >= 12) issueA((nks + c + 4 - P) & 3, have_nxt && nks + c + 4 - P >= 0 && nks + c + 4 - P < nks);   // (rejected where not due: the count is fixed)
         issueW(sg + 4, kw4);
         if (c == 0 && wn == 0 && opaque(lane) == 0)   // the tile after the next, from the class counter
           asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(drawn) : "v"(0), "v"(1), "s"(tile_ctr) : "memory");
