@@ -147,11 +147,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kc9_kernel(const KcArgs) {
       if (__builtin_expect(seg != cur_seg, 0)) set_segment(seg);
       so = (unsigned)(seg ? k - nks1 : k) * 64u;
     }
+    asm volatile("" : "+s"(so));   // a scalar register, never a literal (MUBUF takes none as its scalar offset)
     dma16_asm(srdCur, dstA + (unsigned)((j & 3) * K9_AST), voCur[0], so);
     dma16_asm(srdCur, dstA + (unsigned)((j & 3) * K9_AST + 1024), voCur[1], so);
   };
   auto issueW = [&](int sg, int kw) {     // global stage sg carrying k-step kw
-    const unsigned so = ((w_ks0 + (unsigned)kw) * w_rb32 + w_u0) * 2048u;
+    unsigned so = ((w_ks0 + (unsigned)kw) * w_rb32 + w_u0) * 2048u;
+    asm volatile("" : "+s"(so));
     dma16_asm(srdW, dstW + (unsigned)((sg & 3) * K9_WST), voW, so);
     dma16_asm(srdW, dstW + (unsigned)((sg & 3) * K9_WST + 1024), voW + 1024u, so);
   };
