@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   const int wj0 = wave * 64;
   const int tiles_i = p->tiles_i, tiles_j = p->tiles_j, ntiles = tiles_i * tiles_j;
   const int nks = p->K >> 4, nks1 = p->Ka >> 4;
+  const int eW = *p->EW;                                      // the weight matrix's exponent (read once: a load inside the tile loop is awaited with
+                                                              //  vmcnt(0), i.e. behind the next tile's operand requests)
   const int nst = (nks + 1) >> 1, nst1 = nks1 >> 1;          // stages; stages of the first segment (Ka % 32 == 0 if two)
   constexpr bool ONEPASS = ACT == ACT_SIN;                   // outputs in [-1, 1]: constant block exponent
   constexpr bool BIAS = AUX == AUX_NONE && !COLSUM;           // forward launches; the backward ones (column sums) have none
@@ -137,11 +139,28 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   auto issueA = [&](int S, int slot, int q) {
     dma16(srdCur, dst0 + slot * KC_A + 4096 * q, voCur[q], S < nst ? (unsigned)(S - sbias_st) * 128u : OOB);
   };
-  auto headA = [&]() {                // stages 0 and 1 of the prepared tile
-    enter_stage(0);
-    issueA(0, 0, 0); issueA(0, 0, 1); issueA(0, 0, 2); issueA(0, 0, 3);
-    enter_stage(1);
-    issueA(1, 1, 0); issueA(1, 1, 1); issueA(1, 1, 2); issueA(1, 1, 3);
+  // Stages 0 and 1 of the prepared tile, requested during the previous tile's epilogue -- as asm statements: hipcc cannot tell a
+  // builtin LDS-DMA's destination from the epilogue's LDS strips and would drain it (vmcnt(0)) in front of the first strip
+  // read-back, i.e. wait for the whole latency of the next tile's first stages once per tile.  The descriptor is rebuilt in its
+  // four-word form from the same fields as `srdCur` (segment 1 before the switch stage, segment 2 from it on).
+  auto cur_words = [&]() -> srd_words {
+    const kargs_t a = kargs();
+    if (sbias_st == 0) {
+      const int i0a = (DIAG && (a->dbg & 8)) ? 0 : i0;
+      return make_srd_words(a->A + ((size_t)i0a * a->lda + a->a_col0) * 4, (DIAG && (a->dbg & 1)) ? 0u : clamp_bytes(((unsigned long long)(a->I - i0a - 1) * a->lda + a->Ka) * 4ull));
+    }
+    return make_srd_words(a->A2 + ((size_t)i0 * a->lda2 + a->a2_col0) * 4, clamp_bytes(((unsigned long long)(a->I - i0 - 1) * a->lda2 + (a->K - a->Ka)) * 4ull));
+  };
+  const unsigned dst0_lds = (unsigned)__builtin_amdgcn_readfirstlane(lds_addr(dst0));
+  auto headA = [&]() {
+#pragma unroll
+    for (int S = 0; S < 2; ++S) {
+      enter_stage(S);
+      const srd_words w = cur_words();
+      const unsigned so = S < nst ? (unsigned)(S - sbias_st) * 128u : OOB;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma16_asm(w, dst0_lds + (unsigned)(S * KC_A + 4096 * q), voCur[q], so);
+    }
   };
   struct BFrag { u32x4 h[2], l[2]; };
   // The weight loads are asm statements with their completion counted by hand.  As builtins, hipcc's own vm-counter
@@ -283,20 +302,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 
     // ---- this tile's coordinates for the epilogue; then the next tile's operands are requested ----------------------------
     const int c_ti = ti, c_i0 = i0, c_j0 = j0, c_elast = e_last;
-    const int vbn = dyn ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(lds + KC_NEXT)) : vb + (int)gridDim.x;
+    // the stored activation's block exponent (derivative epilogues): loaded BEFORE the next tile's operands are requested -- the
+    // compiler awaits it with vmcnt(0), which behind those requests costs their whole latency once per tile
+    int eH = 0;
+    if (AUX != AUX_NONE && c_j0 + wj0 < kargs()->J) { const kargs_t a = kargs(); eH = a->EH[(size_t)c_ti * ncb_of(a->ldh) + ((a->h_col0 + c_j0 + wj0) >> 7)]; eH = __builtin_amdgcn_readfirstlane(eH); }
+    // (read on every path: this LDS read is also where hipcc settles its account of the k-loop's builtin DMA requests -- before
+    //  the next tile's requests go out, not in the middle of the epilogue)
+    const int nxt_lds = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(lds + KC_NEXT));
+    const int vbn = dyn ? nxt_lds : vb + (int)gridDim.x;
     const bool more = vbn < ntiles;
-    if (more) {
-      prepare(vbn);
-      if (ONEPASS) headW();
-      headA();
-    }
+    // The next tile's operands.  Forward epilogues request them now; the derivative epilogues first request what they need
+    // themselves at once (sign words, the first two stored-activation half-blocks) -- the counter is in order, and a request
+    // queued behind the next tile's first stages would wait for those.
+    auto next_heads = [&]() {
+      if (more) {
+        prepare(vbn);
+        if (ONEPASS) headW();
+        headA();
+      }
+    };
+    if constexpr (AUX == AUX_NONE) next_heads();
 
     // ---- epilogue.  Lane l: point pt = l & 31 of each 32-point block mi; register r of block (mi, nj) is column
     //      64 wave + 32 nj + 16 (r >> 3) + 8 (l >> 5) + (r & 7) of the tile.  Ring slots 0 and 1 are being refilled; slot 2
     //      and the region behind the ring hold the waves' plane strips (results on their way out) and, for the derivative
     //      epilogues, the stored activations on their way in.
     const kargs_t e = kargs();
-    const int e_in = c_elast + *e->EW;          // acc = true value * 2^e_in
+    const int e_in = c_elast + eW;              // acc = true value * 2^e_in
     const bool e_small = e_in >= -120 && e_in <= 120;
     if (!e_small) {   // exponents beyond a single fp32 factor (never with sane data): scale the accumulators first
 #pragma unroll
@@ -383,8 +415,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       // ---- two passes.  Pass A: final values in place of the accumulators, their |max|, column sums -- one 32-column half
       //      of the wave (nj) after the other, so that only 16 column sums are alive at a time.
       float wmax = 0.f;
-      int eH = 0;
-      if (AUX != AUX_NONE && wave_cols) eH = e->EH[(size_t)c_ti * ncb_of(e->ldh) + ((e->h_col0 + jw) >> 7)];
       const float inv_h = pow2f(-eH);
       // Stored activations (derivative epilogues): half-block hb = (nj, mi) of the wave = 32 points x 128 B, fetched by LDS-DMA
       // in four 1 KiB pieces (8 whole half-rows each) into one of two 4 KiB buffers of the wave (ring slot 2 / the region
@@ -422,6 +452,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       }
       dma_h(0);
       dma_h(1);
+      if constexpr (AUX != AUX_NONE) next_heads();   // (its 8 A pieces are younger than half-blocks 0, 1 and older than the later ones)
       // derivative epilogues: the accumulator's scale and |w0| in one factor; the sign bits are xor-ed with w0's own sign
       const unsigned w0mag = __float_as_uint(fabsf(e->w0) * inv_in);
       const unsigned sflip = e->w0 < 0.f ? 0xFFFFFFFFu : 0u;
@@ -438,7 +469,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
           u32x4 hh[2], hl[2];
           if (AUX != AUX_NONE) {
             // half-block hb (and everything older: the sign words) is home when all but the four pieces of hb + 1 are
-            if (hb == 7) wait_vm<0>(); else wait_vm<4>();
+            // ... and, for half-blocks 0 and 1, the 8 pieces of the next tile's first two A stages requested behind them
+            if (hb == 7) wait_vm<0>(); else if (hb < 2 && more) wait_vm<12>(); else wait_vm<4>();
             const char* hreg = (hb & 1) ? lds + KC_XREG + wave * 4096 : lds + 2 * KC_A + wave * 4096;
             if (AUX == AUX_SINREC && nj == 0) sword[mi] = *reinterpret_cast<const unsigned*>(lds + KC_HSIGN + wave * 1024 + mi * 256 + el * 4) ^ sflip;
 #pragma unroll
@@ -508,7 +540,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       // block maximum: waves 2 c and 2 c + 1 share the exponent block (ti, column block c of the tile)
       wmax = wave_max(wmax);
       if (el == 0) smax[wave] = wmax;
-      __syncthreads();   // also: every wave has finished with the stored-activation buffers the strips share
+      barrier_raw();     // (not __syncthreads(): that drains the vector-memory counter too, behind the next tile's requests and this tile's
+                         //  stores) also: every wave has finished with the stored-activation buffers the strips share
       const float bmax = fmaxf(smax[wave & 2], smax[(wave & 2) + 1]);
       const int eC = exp_of_maxbits(__float_as_uint(bmax));
       const float sc = pow2f(eC);

@@ -45,6 +45,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kc8_kernel(const KcArgs) {
   const int wj0 = wn * 64;
   const int tiles_i = p->tiles_i, tiles_j = p->tiles_j, ntiles = tiles_i * tiles_j;
   const int nks = p->K >> 4, nks1 = p->Ka >> 4;
+  const int eW = *p->EW;                                      // the weight matrix's exponent (read once: a load inside the tile loop is awaited with
+                                                              //  vmcnt(0), i.e. behind the next tile's operand requests)
   const int nrb = (p->I + 127) >> 7;
   constexpr bool ONEPASS = ACT == ACT_SIN;
   constexpr bool BIAS = AUX == AUX_NONE && !COLSUM;
@@ -233,6 +235,13 @@ __global__ __launch_bounds__(512, 2) void gemm_kc8_kernel(const KcArgs) {
 
     // ---- this tile's coordinates for the epilogue; then the next tile's operands are requested ----------------------------
     const int c_i0 = i0, c_j0 = j0, c_elast = e_last;
+    // the stored activation's block exponent (derivative epilogues), loaded BEFORE the next tile's operands are requested (bsp_kc.hip)
+    int eH = 0;
+    {
+      const kargs_t a = kargs();
+      const int r0h = c_i0 + 128 * wm;
+      if (AUX != AUX_NONE && c_j0 + wj0 < a->J && r0h < a->I) { eH = a->EH[(size_t)(r0h >> 7) * ncb_of(a->ldh) + ((a->h_col0 + c_j0 + wj0) >> 7)]; eH = __builtin_amdgcn_readfirstlane(eH); }
+    }
     const int vbn = dyn ? __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(lds + K8_NEXT)) : vb + (int)gridDim.x;
     const bool more = vbn < ntiles;
     if (more) {
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kc8_kernel(const KcArgs) {
     //      and 3 (8 KiB per wave) hold the waves' plane strips (results on their way out) and, for the derivative
     //      epilogues, the stored activations on their way in.
     const kargs_t e = kargs();
-    const int e_in = c_elast + *e->EW;          // acc = true value * 2^e_in
+    const int e_in = c_elast + eW;              // acc = true value * 2^e_in
     const bool e_small = e_in >= -120 && e_in <= 120;
     if (!e_small) {   // exponents beyond a single fp32 factor (never with sane data): scale the accumulators first
 #pragma unroll
@@ -335,8 +344,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kc8_kernel(const KcArgs) {
       // ---- two passes.  Pass A: final values in place of the accumulators, their |max|, column sums -- one 32-column half
       //      of the wave (nj) after the other, so that only 16 column sums are alive at a time.
       float wmax = 0.f;
-      int eH = 0;
-      if (AUX != AUX_NONE && wave_cols) eH = e->EH[(size_t)rbw * ncb_of(e->ldh) + ((e->h_col0 + jw) >> 7)];
       const float inv_h = pow2f(-eH);
       // Stored activations (derivative epilogues): half-block hb = (nj, mi) of the wave = 32 points x 128 B, fetched by LDS-DMA
       // in four 1 KiB pieces (8 whole half-rows each) into one of two 4 KiB buffers of the wave (inside ring slots 2, 3), half-block hb + 1 while hb is worked on.  Chunk c of point row q lies at position c ^ ((q >> 1) & 7)
