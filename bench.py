@@ -284,21 +284,48 @@ def main():
 
     step = 0
     for _ in range(args.warmup):
-        loop.step(step)
+        out = loop.step(step)      # held like in the timed loop: the warm-up must have the timed region's memory profile
         step += 1
     barrier()
-    # per-step marks on the compute stream (no host sync inside the timed region): the median step time next to the mean
+    # per-step marks on the compute stream (no host sync inside the timed region) and the host's wall clock at the same points:
+    # the line carries BOTH series in issue order, so a stall can be placed (which step) and attributed (device or host).
+    import gc
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    host_t = [0.0] * (args.steps + 1)
+    gc.collect()
+    gc.freeze()          # nothing allocated before this point is ever scanned again
+    gc_was = gc.isenabled()
+    gc.disable()         # no collector pause inside the timed region (re-enabled right after it)
+    mem0 = torch.cuda.memory_stats(device)
     t0 = time.perf_counter()
     marks[0].record()
+    host_t[0] = t0
     for i in range(args.steps):
         out = loop.step(step)
         marks[i + 1].record()
+        host_t[i + 1] = time.perf_counter()
         step += 1
+    t_issued = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    if gc_was:
+        gc.enable()
+    mem1 = torch.cuda.memory_stats(device)
+    step_ms_issue = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    host_step_ms = [(host_t[i + 1] - host_t[i]) * 1e3 for i in range(args.steps)]
+    step_ms = sorted(step_ms_issue)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    i_max = max(range(args.steps), key=lambda i: step_ms_issue[i])
+    timing = {
+        "step_ms": [round(x, 3) for x in step_ms_issue],             # device time between consecutive step marks, issue order
+        "host_step_ms": [round(x, 3) for x in host_step_ms],         # host wall time to ISSUE each step (launches are asynchronous)
+        "device_sum_ms": sum(step_ms_issue), "wall_ms": dt * 1e3, "host_issue_ms": (t_issued - t0) * 1e3,
+        "max_step_ms": step_ms_issue[i_max], "max_step_index": i_max,
+        "host_max_step_ms": max(host_step_ms), "host_max_step_index": max(range(args.steps), key=lambda i: host_step_ms[i]),
+        "allocator_delta": {k: int(mem1.get(k, 0) - mem0.get(k, 0)) for k in
+                            ("num_alloc_retries", "num_device_alloc", "num_device_free", "num_ooms", "reserved_bytes.all.current")},
+        "gc": "frozen + disabled over the timed region",
+    }
     # Roofline phase (after the timed region, so the headline number carries no event overhead): the same steps with
     # the main and solar-correction passes serialised -- in the timed region their kernels overlap on two HIP streams,
     # which would stretch every per-kernel duration -- and every GEMM launch bracketed by HIP events on its stream.
@@ -338,7 +365,7 @@ def main():
     line = {
         "metric": f"train rays/sec ({args.rays} rays x {args.samples} samples)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": median_ms,
-        "higher_is_better": True, "scaling": "weak",
+        "higher_is_better": True, "scaling": "weak", "timing": timing,
         # BASELINE.md holds no published number for this metric (the reference publishes none): null by the contract.  The
         # north-star ratio against the reference's single-GPU PyTorch path measured in THIS run is `vs_reference_gpu_eager`.
         "vs_baseline": None,

@@ -292,6 +292,7 @@ int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, 
                     float* C, int ldc, int I, int J, int K, int narrow, void* stream);
 /* test hooks of the block-scaled fp16-plane kernels (csrc/bsp.h): fp32 in / fp32 out around one launch; synchronous and
  * allocating -- tests only */
+int snerf_test_set_kc_grid(int n_workgroups);   /* persistent grid of the K-contiguous launches (0: two per CU): forces the tile loop at test sizes */
 int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int col0, float* dst, int* exps_out, void* stream);
 int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, const float* bias, int I, int J, int K, int a_col0,
                       int c_col0, int act, float w0, int aux_mode, const float* Hact, const unsigned* Hsign, float* C,

@@ -133,6 +133,8 @@ def lib():
     L.snerf_test_gemm.restype = C.c_int
     L.snerf_test_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.snerf_test_set_kc_grid.restype = C.c_int
+    L.snerf_test_set_kc_grid.argtypes = [C.c_int]
     L.snerf_test_bsp_roundtrip.restype = C.c_int
     L.snerf_test_bsp_roundtrip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.snerf_test_bsp_kc.restype = C.c_int
@@ -177,4 +179,4 @@ EXPORTED_SYMBOLS = ("snerf_version", "snerf_last_error", "snerf_packed_floats", 
                     "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward", "snerf_test_gemm",
                     "snerf_loss_workspace_bytes", "snerf_loss_partial", "snerf_loss_finish", "snerf_profile_begin",
                     "snerf_profile_end", "snerf_sample_z", "snerf_adam_step", "snerf_test_bsp_roundtrip", "snerf_test_bsp_kc",
-                    "snerf_test_bsp_dw", "snerf_embedding_rows", "snerf_embedding_backward")
+                    "snerf_test_bsp_dw", "snerf_test_set_kc_grid", "snerf_embedding_rows", "snerf_embedding_backward")

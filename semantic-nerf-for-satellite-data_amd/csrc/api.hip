@@ -803,6 +803,10 @@ int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int c
   return SNERF_OK;
 }
 
+// persistent grid of the K-contiguous launches: n workgroups instead of two per CU (0: default) -- small test problems then walk
+// several tiles per workgroup and draw them from the tile counters
+int snerf_test_set_kc_grid(int n) { bsp::kc_set_grid_override(n); return SNERF_OK; }
+
 // C[I][J] = epilogue(A[I][Ka] | A2[I][K-Ka]) . W[J][K]^T).  The A tensors are placed at column a_col0 of wider plane
 // tensors and the output at column c_col0 (exercises the column-offset / exponent-block arithmetic).
 int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, const float* bias, int I, int J, int K, int a_col0,

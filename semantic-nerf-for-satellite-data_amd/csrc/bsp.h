@@ -112,7 +112,6 @@ struct KcArgs {
   const char* H = nullptr; const int* EH = nullptr; int ldh = 0; int h_col0 = 0; const unsigned* Hsign = nullptr;
   float* colsum = nullptr; int ldcs = 0;   // partial column sums of the stored values, one row per 128-row tile (bias gradients)
   int tiles_i = 0, tiles_j = 0;
-  int n_grp = 0;                     // bsp_kc9.hip: XCD groups of the launch (8 or 1)
   int rev = 0;                       // walk the tiles of every XCD group backwards (tiles.h)
   int dbg = 0;                       // diagnostic builds only (bsp_kc.hip: DIAG); ignored by the product kernels
   int* tile_ctr = nullptr;           // 8 zeroed ints (one 64-byte slot per launch): tiles beyond the first are drawn from them; null: fixed shares
@@ -132,6 +131,7 @@ struct DwArgs {
 };
 
 int launch_kc(const KcArgs& a, hipStream_t st);          // 128 x 256 tiles, BSP output
+void kc_set_grid_override(int n);                          // test hook: persistent grid of n workgroups (0: two per CU)
 int launch_kc_narrow(const KcArgs& a, hipStream_t st);   // 128 x 32 tiles, fp32 output (Cf), bias only
 int launch_dw(const DwArgs& a, bool narrow_i, hipStream_t st);   // 256 x 256 tiles (narrow_i: 32 x 256)
 

@@ -577,19 +577,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 int prof_hook_begin(double flops, int variant, hipStream_t st);   // gemm.hip: per-launch HIP events when profiling is on
 void prof_hook_end(int token, hipStream_t st);
 int check_kc(const KcArgs& a, bool narrow);                        // bsp_gemm.hip
-int launch_kc8(KcArgs a, bool sin_hw, hipStream_t st);             // bsp_kc8.hip
-int launch_kc9(KcArgs a, bool sin_hw, hipStream_t st);             // bsp_kc9.hip (-1: does not qualify)
+static int sin_mode() { return SIN_HW; }   // v_sin_f32 on the reduced argument; SIN_POLY (degree-9 polynomial) is the test-only alternative of tools/ablate
 
-static int sin_mode() {   // SNERF_SIN=poly: the polynomial instead of v_sin_f32 (A/B; read once)
-  static const int m = [] { const char* e = getenv("SNERF_SIN"); return (e && e[0] == 'p') ? SIN_POLY : SIN_HW; }();
-  return m;
-}
-
-// workgroup slots of the device: two 256-thread workgroups per CU (registers, LDS).  SNERF_KC_GRID=<n> (tests) forces a
-// small grid so that small problems exercise the tile loop.  Read once: nothing here runs per launch.
+// workgroup slots of the device: two 256-thread workgroups per CU (registers, LDS).  snerf_test_set_kc_grid (test hook of the
+// C-ABI) forces a small grid so that small problems exercise the tile loop and the tile counters.
+static int g_kc_grid_override = 0;
+void kc_set_grid_override(int n) { g_kc_grid_override = n > 0 ? n : 0; }
 static int kc_slots() {
+  if (g_kc_grid_override > 0) return g_kc_grid_override;
   static const int n = [] {
-    if (const char* e = getenv("SNERF_KC_GRID")) { const int v = atoi(e); if (v > 0) return v; }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     return 2 * cus;
@@ -597,14 +593,6 @@ static int kc_slots() {
   return n;
 }
 
-static bool kc_wide() {   // SNERF_KC=8: the 256 x 256 kernel of bsp_kc8.hip (A/B; read once)
-  static const bool w = [] { const char* e = getenv("SNERF_KC"); return e && e[0] == '8'; }();
-  return w;
-}
-static bool kc_staggered() {   // SNERF_KC=9: SIREN forward launches on the staggered-halves kernel of bsp_kc9.hip (A/B; read once)
-  static const bool w = [] { const char* e = getenv("SNERF_KC"); return e && e[0] == '9'; }();
-  return w;
-}
 static bool cs_bias_check(const KcArgs& a) {
   if (a.colsum != nullptr && a.bias != nullptr) { set_error("bsp gemm: bias and column sums in one launch"); return true; }
   return false;
@@ -616,8 +604,6 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   int rc = check_kc(a, false);
   if (rc) return rc;
   if (cs_bias_check(a)) return SNERF_ERR_BAD_DESC;
-  if (kc_wide()) return launch_kc8(a, sin_mode() == SIN_HW, st);
-  if (kc_staggered()) { const int r9 = launch_kc9(a, sin_mode() == SIN_HW, st); if (r9 >= 0) return r9; }
   a.tiles_i = (a.I + 127) / 128;
   a.tiles_j = (a.J + 255) / 256;
 #ifdef KC_DIAG_BUILD

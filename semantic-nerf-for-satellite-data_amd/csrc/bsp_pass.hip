@@ -13,11 +13,8 @@ namespace snerf {
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
 
 namespace {
-// SNERF_KC_STATIC=1 (diagnostic): fixed tile shares instead of the per-launch tile counters
-bool kc_static_tiles() { static const bool v = [] { const char* e = getenv("SNERF_KC_STATIC"); return e && e[0] == '1'; }(); return v; }
 // Every other K-contiguous launch of a pass walks its tiles backwards (tiles.h): a consumer starts with the rows its producer
-// wrote last.  Measured 372.0 -> 369.8 us per launch, 28.27 -> 28.12 ms per step (two A/B pairs on one box); SNERF_KC_ALT=0: off.
-bool kc_alternate() { static const bool v = [] { const char* e = getenv("SNERF_KC_ALT"); return !(e && e[0] == '0'); }(); return v; }
+// wrote last.  Measured 372.0 -> 369.8 us per launch, 28.27 -> 28.12 ms per step (two A/B pairs on one box).
 struct Ws {
   char* base;
   char* c(size_t off) const { return base + off; }
@@ -43,7 +40,7 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
   // captured HIP graph, and replays on ROCm 7.2 then ran the backward's launches on counters that had not been zeroed.)
   RC(bsp::launch_zero_cols(ws.c(p.o_kcq), (size_t)KCQ_SLOTS * 64, (size_t)KCQ_SLOTS * 64, 1, st));
   int kcq = 0;
-  auto launch_kc = [&](bsp::KcArgs& g) { g.rev = kc_alternate() ? (kcq & 1) : 0; g.tile_ctr = (kcq < KCQ_SLOTS && !kc_static_tiles()) ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
+  auto launch_kc = [&](bsp::KcArgs& g) { g.rev = kcq & 1; g.tile_ctr = kcq < KCQ_SLOTS ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
   const int P = p.P, W = p.W, H = p.H;
   float* z = ws.f(p.o_z);
   // 1. depths
@@ -207,7 +204,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
   const int P = p.P, W = p.W, H = p.H;
   RC(bsp::launch_zero_cols(ws.c(p.o_kcq), (size_t)KCQ_SLOTS * 64, (size_t)KCQ_SLOTS * 64, 1, st));
   int kcq = 0;
-  auto launch_kc = [&](bsp::KcArgs& g) { g.rev = kc_alternate() ? (kcq & 1) : 0; g.tile_ctr = (kcq < KCQ_SLOTS && !kc_static_tiles()) ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
+  auto launch_kc = [&](bsp::KcArgs& g) { g.rev = kcq & 1; g.tile_ctr = kcq < KCQ_SLOTS ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
   // activation derivative in a dX epilogue, rebuilt from the stored activation h (planes o_h / exponents e_h, leading
   // dimension ld, column col0): siren w0 * sign(cos) * sqrt(1 - h^2) with the sign words o_c; relu: h > 0
   auto dact = [&](bsp::KcArgs& g, size_t o_c, size_t o_h, size_t e_h, int ld, int col0 = 0, float w0 = 1.f) {

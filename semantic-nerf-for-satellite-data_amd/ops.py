@@ -142,6 +142,68 @@ def _empty(*a, **k):
     return t
 
 
+# ---- pass workspaces -------------------------------------------------------------------------------------------------
+# A training pass needs 8-20 GB of workspace between its forward and its backward.  Taking it from torch's caching allocator
+# every step works until something else is allocated while the block lies free: the allocator carves a few MB for a result
+# tensor out of the free 10 GB block, the next forward finds no block of its size and goes to hipMalloc (10 GB: milliseconds
+# on a quiet box, a quarter of a second on a busy one) in the middle of training.  Workspaces are therefore LEASED from a pool
+# of whole tensors keyed by (device, stream, size): a lease ends in the pass's backward (or when its autograd node dies) and the
+# same tensor serves the same pass of the next step on the same stream, so stream order alone makes the reuse safe.
+_WS_FREE: dict = {}                 # (device index, stream id, nbytes) -> [tensor, ...]
+_WS_FREE_BYTES = 0
+_WS_POOL_CAP = int(float(os.environ.get("SNERF_WS_POOL_GB", "96")) * (1 << 30))   # idle bytes kept; beyond it the oldest idle workspaces go back to torch
+
+
+class _WsLease:
+    __slots__ = ("key", "t")
+
+    def __init__(self, key, t):
+        self.key, self.t = key, t
+
+    def release(self):
+        global _WS_FREE_BYTES
+        t, self.t = self.t, None
+        if t is None:
+            return
+        _WS_FREE.setdefault(self.key, []).append(t)
+        _WS_FREE_BYTES += t.numel()
+        while _WS_FREE_BYTES > _WS_POOL_CAP and _WS_FREE:
+            k = next(iter(_WS_FREE))          # dicts keep insertion order: the key idle for longest first
+            lst = _WS_FREE[k]
+            _WS_FREE_BYTES -= lst.pop(0).numel()
+            if not lst:
+                del _WS_FREE[k]
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:      # interpreter shutdown: the module's globals may be gone
+            pass
+
+
+def lease_workspace(dev, nbytes: int) -> _WsLease:
+    global _WS_FREE_BYTES
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream, int(nbytes))
+    lst = _WS_FREE.get(key)
+    if lst:
+        t = lst.pop()
+        _WS_FREE_BYTES -= t.numel()
+        if not lst:
+            del _WS_FREE[key]
+        if _WS_POISON:
+            t.fill_(0xFF)
+    else:
+        t = _empty(nbytes, dtype=torch.uint8, device=dev)
+    return _WsLease(key, t)
+
+
+def release_workspaces():
+    """hand every idle workspace back to torch's allocator (before a phase with another memory profile, e.g. full-frame inference)"""
+    global _WS_FREE_BYTES
+    _WS_FREE.clear()
+    _WS_FREE_BYTES = 0
+
+
 def _empty_like(x):
     t = torch.empty_like(x)
     if _WS_POISON and t.numel():
@@ -361,7 +423,9 @@ class _RenderPass(torch.autograd.Function):
         nbytes = L.snerf_workspace_bytes(C.byref(d))
         if nbytes == 0:
             _lib.check(1, "snerf_workspace_bytes")
-        ws = _empty(nbytes, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            lease = lease_workspace(dev, nbytes)
+        ws = lease.t
         keys = output_keys(spec, sc_pass)
         outs = {k: _empty(_OUT_SHAPES[k](N, S, spec.n_classes), dtype=torch.float32, device=dev) for k in keys}
         label = _empty((N,), dtype=torch.int64, device=dev) if (spec.n_classes > 0 and not sc_pass) else None
@@ -378,7 +442,9 @@ class _RenderPass(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(L.snerf_forward(C.byref(d), _ptr(packed), C.byref(si), C.byref(so), _ptr(ws), nbytes,
                                        _stream()), "snerf_forward")
-        ctx.spec, ctx.pin, ctx.desc, ctx.ws, ctx.nbytes = spec, pin, d, ws, nbytes
+        if not need_grad:
+            lease.release()    # nothing is kept for a backward: the next pass of this size on this stream may have it
+        ctx.spec, ctx.pin, ctx.desc, ctx.lease, ctx.nbytes = spec, pin, d, lease, nbytes
         ctx.packed, ctx.names, ctx.keys, ctx.tc, ctx.tsc = packed, names, keys, tc, tsc
         ctx.param_like = params
         ctx.train = need_grad
@@ -395,6 +461,8 @@ class _RenderPass(torch.autograd.Function):
         if not ctx.train:
             raise RuntimeError("snerf_amd: backward through a pass that was run without SNERF_FLAG_TRAIN")
         spec, d = ctx.spec, ctx.desc
+        if ctx.lease.t is None:
+            raise RuntimeError("snerf_amd: second backward through one pass (its workspace went back to the pool after the first)")
         go = _lib.SnerfOutGrads()
         keep, live = [], []
         for k, g in zip(ctx.keys, gouts[:ctx.n_diff]):
@@ -412,9 +480,9 @@ class _RenderPass(torch.autograd.Function):
         si = ctx.pin.struct(ctx.tc, ctx.tsc)
         with torch.cuda.device(dev):
             _lib.check(L.snerf_backward(C.byref(d), _ptr(ctx.packed), C.byref(si), C.byref(go), _ptr(pg), _ptr(d_t),
-                                        _ptr(d_ts), _ptr(ctx.ws), ctx.nbytes, _stream()), "snerf_backward")
+                                        _ptr(d_ts), _ptr(ctx.lease.t), ctx.nbytes, _stream()), "snerf_backward")
         like = dict(zip(ctx.names, ctx.param_like))
-        ctx.ws = None
+        ctx.lease.release()
         sinks = _sinks_for(ctx.param_like)
         if sinks is not None:
             with torch.cuda.device(dev):

@@ -57,6 +57,17 @@ def test_planes_round_trip_and_block_exponents():
             assert 2.0 ** 13 <= m * 2.0 ** e < 2.0 ** 14, (rb, cb, e, m)
 
 
+@pytest.fixture(params=[0, 3, 2], ids=["grid_default", "grid_3_workgroups", "grid_2_workgroups"])
+def kc_grid(request):
+    """Every K-contiguous case runs with the default persistent grid (two workgroups per CU: one tile each at these sizes) and
+    with a forced grid of 3 / 2 workgroups (snerf_test_set_kc_grid), where every workgroup walks several tiles and draws them
+    from the tile counters: the tile loop, the next-tile prefetch during the epilogue and the hand-counted waits behind it."""
+    L, _ = _lib()
+    L.snerf_test_set_kc_grid(request.param)
+    yield request.param
+    L.snerf_test_set_kc_grid(0)
+
+
 def _kc(A, W, bias=None, A2=None, act=ACT_NONE, w0=1.0, aux=AUX_NONE, Hact=None, Hsign=None, a_col0=0, c_col0=0,
         want_sign=False, want_colsum=False, narrow=False):
     L, lib = _lib()
@@ -73,7 +84,7 @@ def _kc(A, W, bias=None, A2=None, act=ACT_NONE, w0=1.0, aux=AUX_NONE, Hact=None,
 
 
 @pytest.mark.parametrize("I,J,K", [(128, 256, 16), (300, 512, 512), (1000, 544, 528), (257, 48, 64), (4096, 1024, 544)])
-def test_kc_plain_and_bias(I, J, K):
+def test_kc_plain_and_bias(I, J, K, kc_grid):
     g = torch.Generator().manual_seed(I + J + K)
     A = torch.randn(I, K, generator=g).to(DEV)
     W = (torch.randn(J, K, generator=g) * 0.05).to(DEV)
@@ -91,7 +102,7 @@ def test_kc_plain_and_bias(I, J, K):
     assert _relerr(cs, want) <= 1e-5
 
 
-def test_kc_two_segments_offsets_and_exponent_changes():
+def test_kc_two_segments_offsets_and_exponent_changes(kc_grid):
     """[gamma | h] style two-segment A, A placed at a column offset, output at a column offset, and A blocks whose
     magnitudes differ by 2^20 along k: the accumulators are rescaled between column blocks (and segments)"""
     g = torch.Generator().manual_seed(7)
@@ -120,7 +131,7 @@ def test_kc_two_segments_offsets_and_exponent_changes():
 
 
 @pytest.mark.parametrize("I,J,K,w0", [(300, 512, 64, 30.0), (1000, 1024, 544, 1.0)])
-def test_kc_siren_forward_then_derivative_epilogue(I, J, K, w0):
+def test_kc_siren_forward_then_derivative_epilogue(I, J, K, w0, kc_grid):
     """forward: h = sin(w0 (x W^T + b)) + sign words of cos; backward epilogue: (g W2^T) * w0 cos(w0 z) rebuilt from the
     stored h and the sign bits, + column sums"""
     g = torch.Generator().manual_seed(I + K)
@@ -145,7 +156,7 @@ def test_kc_siren_forward_then_derivative_epilogue(I, J, K, w0):
     assert _relerr(cs, want) <= 1e-4
 
 
-def test_kc_relu_forward_and_mask():
+def test_kc_relu_forward_and_mask(kc_grid):
     g = torch.Generator().manual_seed(11)
     I, J, K = 520, 256, 96
     X = torch.randn(I, K, generator=g).to(DEV)
@@ -258,21 +269,3 @@ def test_vanishing_blocks_next_to_loud_ones_stay_finite():
     refd = Zs.double().T @ Xs.double()
     assert bool(torch.isfinite(Cd).all())
     assert _relerr(Cd, refd) <= max(2.0 * _relerr(Zs.T @ Xs, refd), 3e-7)
-
-
-@pytest.mark.parametrize("env", [{"SNERF_KC_GRID": "3"}, {"SNERF_KC": "8"}, {"SNERF_KC": "8", "SNERF_KC_GRID": "2"},
-                                 {"SNERF_KC": "9"}, {"SNERF_KC": "9", "SNERF_KC_GRID": "2"}],
-                         ids=["tile_loop_forced", "wide_256x256", "wide_tile_loop_forced", "staggered_halves", "staggered_tile_loop_forced"])
-def test_kc_variants_in_a_child_process(env):
-    """The library reads its switches once per process, so the K-contiguous cases above run again in a child process:
-    with a persistent grid of 3 / 2 workgroups (every workgroup walks several tiles and draws them from the counters even
-    at these small sizes), on the 256 x 256 kernel of csrc/bsp_kc8.hip (SNERF_KC=8) and with the SIREN forward launches on the
-    staggered-halves kernel of csrc/bsp_kc9.hip (SNERF_KC=9) -- same C-ABI, same results."""
-    import os
-    import subprocess
-    import sys
-    e = dict(os.environ, **env)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
-                        "-k", "test_kc_ and not narrow and not child_process"], env=e, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
