@@ -190,7 +190,7 @@ def rehearsal(args):
     from snerf_amd import parallel
     if os.environ.get("SNERF_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):   # test hook: a rank that dies at start-up
         raise SystemExit(3)
-    rank, world, device = parallel.init_distributed("gloo" if not torch.cuda.is_available() else None)
+    rank, world, device = parallel.init_distributed("gloo")   # the rehearsal's tensors live on the host whatever the box has
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     bucket = torch.zeros(2_826_766 + 200, dtype=torch.float32)   # the flat gradient bucket
@@ -276,6 +276,8 @@ def main():
     pipe = load_pipeline(cfgs)
     pipe.log_metrics = False  # the reference logs per-step scalars lazily; no host sync inside the timed region
     loop = TrainLoop(pipe, cfgs, device)
+    if world > 1:
+        loop.exchange_events = []     # HIP events around every step's gradient all-reduce (read after the timed region)
 
     def barrier():
         if world > 1:
@@ -308,6 +310,11 @@ def main():
     t_issued = time.perf_counter()
     barrier()
     dt = time.perf_counter() - t0
+    exchange_ms = None
+    if loop.exchange_events:
+        ev = loop.exchange_events[-args.steps:]          # the timed steps' events (the warm-up's come first)
+        exchange_ms = [a.elapsed_time(b) for a, b in ev]
+        loop.exchange_events = None
     if gc_was:
         gc.enable()
     mem1 = torch.cuda.memory_stats(device)
@@ -391,6 +398,12 @@ def main():
         line["config"]["distributed"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                                          "nccl_version": ".".join(map(str, torch.cuda.nccl.version())) if dist.get_backend() == "nccl" else None,
                                          "gradient_bucket_floats": int(getattr(loop.optimizer, "numel", 0))}
+        if exchange_ms:   # compute vs exchange, from the first SCALE record on: device time of the flat gradient all-reduce per step (rank 0)
+            xs = sorted(exchange_ms)
+            line["config"]["distributed"]["allreduce_ms_per_step"] = {"mean": sum(xs) / len(xs), "median": xs[len(xs) // 2], "max": xs[-1],
+                                                                       "bytes": 4 * int(getattr(loop.optimizer, "numel", 0)),
+                                                                       "note": "HIP events on the compute stream around dist.all_reduce(flat gradient bucket); "
+                                                                               "includes waiting for the slowest rank's backward"}
     step_tflops = flops_step_gpu * args.steps / dt / 1e12  # per GPU, algorithmic (SURVEY 8d figure)
     if prof is not None:
         x6 = mode != "fp32"

@@ -5,7 +5,7 @@ rasterisation and the normals variants stay with the dataset / CPU tooling (SURV
 import numpy as np
 import torch
 
-from .utils.util import lean_inference
+from .utils.util import lean_inference, sharded_lean_inference
 
 
 def get_xyz_from_nerf_prediction(rays: torch.Tensor, depth: torch.Tensor) -> torch.Tensor:
@@ -16,13 +16,19 @@ def get_xyz_from_nerf_prediction(rays: torch.Tensor, depth: torch.Tensor) -> tor
 
 
 @torch.no_grad()
-def extract_pointcloud(cfgs, renderer, models, rays, extras, render_options=None, with_labels=None):
-    """One image -> {"xyz_n" (R,3) f64, "colors" (R,3) f32, "depth" (R) f32 [, "labels" (R) i64]}, all on the device."""
+def extract_pointcloud(cfgs, renderer, models, rays, extras, render_options=None, with_labels=None, sharded=None):
+    """One image -> {"xyz_n" (R,3) f64, "colors" (R,3) f32, "depth" (R) f32 [, "labels" (R) i64]}, all on the device.
+    Under a process group (`sharded` None: whenever world size > 1) the image's rays are rendered in rank shards and the
+    per-ray results gathered, so every rank returns the whole cloud (eval/utils/util.py: sharded_lean_inference)."""
+    from .. import parallel
+    if sharded is None:
+        sharded = parallel.world()[1] > 1
     sem = models["coarse"].spec.n_classes > 0
     if with_labels is None:
         with_labels = sem
     keys = ["rgb_coarse", "depth_coarse"] + (["semantic_label_coarse"] if with_labels and sem else [])
-    res = lean_inference(cfgs, renderer, models, rays, extras, keys=keys, render_options=render_options or {})
+    infer = sharded_lean_inference if sharded else lean_inference
+    res = infer(cfgs, renderer, models, rays, extras, keys=keys, render_options=render_options or {})
     out = {"xyz_n": get_xyz_from_nerf_prediction(rays, res["depth_coarse"]), "colors": res["rgb_coarse"],
            "depth": res["depth_coarse"]}
     if "semantic_label_coarse" in res:

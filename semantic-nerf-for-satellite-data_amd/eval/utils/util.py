@@ -76,3 +76,46 @@ def lean_inference(cfgs, renderer, models, rays, extras, keys=("rgb_coarse", "de
         ws = renderer.render_rays_into(models, rays[i:i + chunk], extras[i:i + chunk] if extras is not None else None,
                                        sl, opts)
     return out
+
+
+PER_RAY_RESULTS = ("rgb", "depth", "semantic_label", "semantic_logits")   # (N, ...) results: what a frame / point cloud is made of
+
+
+def shard_and_gather(render_rows, n: int, rank: int = None, world: int = None) -> dict:
+    """`render_rows(lo, hi)` -> dict of results for the rays [lo, hi) of an n-ray frame; this rank renders its contiguous
+    slice (parallel.frame_shard) and the per-ray results (PER_RAY_RESULTS, with or without the `_coarse` postfix) are
+    all-gathered into full-frame tensors on every rank -- ragged tails and empty shards included.  Per-sample results
+    ((N, S, ...): weights, sigmas, ...) stay local under their key; `out["_rows"]` = (lo, hi) names the rows they cover."""
+    from ... import parallel
+    lo, hi = parallel.frame_shard(n, rank, world)
+    local = render_rows(lo, hi)
+    out = {"_rows": (lo, hi)}
+    for k, v in local.items():
+        bare = k[:-len("_coarse")] if k.endswith("_coarse") else k
+        out[k] = parallel.allgather_rows(v, n) if bare in PER_RAY_RESULTS else v
+    return out
+
+
+@torch.no_grad()
+def sharded_lean_inference(cfgs, renderer, models, rays, extras, keys=("rgb_coarse", "depth_coarse", "semantic_label_coarse"),
+                           render_options={}, show_tqdm=False):
+    """lean_inference with the frame's rays sharded over the ranks of the process group (SURVEY 8(e), config 5's full-frame
+    half; reference callers eval/utils/util.py:13-42, eval/extract_pointcloud.py:66-114 are single-device): every rank holds
+    the frame's rays, renders rows frame_shard(n) of them and receives the per-ray results of all ranks; the exchange is one
+    all_gather per requested per-ray result (rgb: 12 B, depth: 4 B, label: 8 B per ray).  Equal to lean_inference on one rank
+    bit for bit (rays are independent; per-ray jitter given for the whole frame is sliced with the rays)."""
+    n = rays.shape[0]
+
+    def rows(lo, hi):
+        if hi == lo:      # more ranks than rays: contribute nothing (a zero-ray launch has no defined result)
+            S, Cn = cfgs.pipeline.n_samples, models["coarse"].spec.n_classes
+            out = {}
+            for k in keys:
+                bare = k[:-len("_coarse")] if k.endswith("_coarse") else k
+                dt = torch.int64 if bare == "semantic_label" else torch.float32
+                out[bare + "_coarse"] = torch.empty((0,) + _KEY_SHAPES[bare](S, Cn), dtype=dt, device=rays.device)
+            return out
+        opts = _chunk_options(render_options, lo, hi - lo, n) if n > hi - lo else render_options
+        return lean_inference(cfgs, renderer, models, rays[lo:hi], extras[lo:hi] if extras is not None else None, keys=keys,
+                              render_options=opts, show_tqdm=show_tqdm)
+    return shard_and_gather(rows, n)

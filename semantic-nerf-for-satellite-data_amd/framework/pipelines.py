@@ -122,6 +122,7 @@ class TrainLoop:
         self.params = [p for p in pipeline.parameters() if p.requires_grad]
         self.bucket = None
         self.shuffle = bool(cfgs.run.shuffle_dataset)
+        self.exchange_events = None      # bench: a list -> (start, end) HIP events around the gradient all-reduce of every step
 
     def step(self, step: int):
         pl = self.pipeline
@@ -137,7 +138,15 @@ class TrainLoop:
         if hasattr(self.optimizer, "flat_g"):
             # every .grad is a view of the optimiser's flat gradient buffer: it is the all-reduce bucket
             self.optimizer._collect_foreign_grads()
-            self.bucket = parallel.allreduce_sum_(self.optimizer.flat_g)
+            if self.exchange_events is not None and self.world > 1:
+                ops.wait_grad_sinks(self.device)      # what the collective waits for anyway: keep it out of the measured interval
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                self.bucket = parallel.allreduce_sum_(self.optimizer.flat_g)
+                ev[1].record()
+                self.exchange_events.append(ev)
+            else:
+                self.bucket = parallel.allreduce_sum_(self.optimizer.flat_g)
         else:
             self.bucket = parallel.allreduce_gradients(self.params, self.bucket)
         self.optimizer.step()
@@ -154,6 +163,8 @@ class TrainLoop:
         (eval/eval_semantic.py:63-77,122-140) -- one host read at the very end.  Ranks share each image's rays."""
         pl = self.pipeline
         bank = pl.datasets["rgb_test"]
+        # NOTE: the package's only bank factory is the synthetic one (GpuRayBank.synthetic, no image sizes), so from the product's
+        # own data path the means below are per-SLICE means; a loader of real data passes `image_sizes` to GpuRayBank.
         # images: the bank's own per-image ray counts where it carries them (real data: the reference's per-image means,
         # framework/pipelines.py:120-129, eval_semantic.py:63-77); else equal slices of `rays_per_image` rows -- a SYNTHETIC
         # definition of "image" (the means are then per-slice means)

@@ -53,6 +53,37 @@ def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def frame_shard(n: int, rank: int = None, world_size: int = None):
+    """contiguous slice [lo, hi) of a frame of n rays for this rank: ceil(n / world) rays per rank, the last ranks take the ragged
+    tail (possibly nothing).  SURVEY 8(e): "shard the H*W rays of each image across ranks"."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    per = -(-n // world_size)
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n)
+
+
+def allgather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """Rows of a per-ray result, sharded by frame_shard, -> the full (n_total, ...) tensor on EVERY rank: one all_gather of
+    equal ceil(n / world)-row pieces (short shards are padded, the padding is cut off again).  Single process: the input."""
+    _, w = world()
+    if w == 1:
+        return local
+    per = -(-n_total // w)
+    piece = local
+    if local.shape[0] != per:
+        piece = local.new_zeros((per,) + tuple(local.shape[1:]))
+        piece[:local.shape[0]] = local
+    piece = piece.contiguous()
+    hop = piece.is_cuda and dist.get_backend() == "gloo"      # test rigs only: gloo ranks sharing one GPU
+    src = piece.cpu() if hop else piece
+    parts = [torch.empty_like(src) for _ in range(w)]
+    dist.all_gather(parts, src)
+    full = torch.cat(parts, 0)[:n_total]
+    return full.to(local.device) if hop else full
+
+
 def allreduce_gradients(params, flat_buffer: torch.Tensor = None) -> torch.Tensor:
     """Sum-all-reduce every .grad through one flat bucket (a single RCCL call): one cat kernel in, one fused
     multi-tensor copy out. Returns the bucket."""

@@ -46,3 +46,7 @@ def test_bench_two_ranks_plain_command_on_one_gpu():
               "--no-eager-gpu-baseline", "--no-inference", "--no-profile"], {"SNERF_DIST_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["config"]["distributed"]["world_size"] == 2 and d["config"]["global_batch"] == 512
     assert d["value"] > 0 and d["data"] == "synthetic"
+    # the exchange is timed apart from the compute (HIP events around the flat gradient all-reduce of every timed step)
+    ar = d["config"]["distributed"]["allreduce_ms_per_step"]
+    assert ar["mean"] >= 0 and ar["max"] >= ar["median"] and ar["bytes"] > 0
+    assert len(d["timing"]["step_ms"]) == 2 and len(d["timing"]["host_step_ms"]) == 2

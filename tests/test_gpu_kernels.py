@@ -15,7 +15,11 @@ from tests.helpers import load_fixture, fixture_params, fixture_batch, max_abs, 
 pytestmark = pytest.mark.gpu
 
 OUT_TOL = 1e-4
-GRAD_REL_TOL = 2e-3  # relative L2 per parameter tensor (fp32 chains of different summation order)
+# relative L2 per parameter tensor, default (fp32-class) arithmetic: 10x the largest error MEASURED on any tensor of any case
+# (1e-6 ... 4e-5; fp32 chains of different summation order on both sides).  A backward kernel that lost 4 bits fails this.
+GRAD_REL_TOL = 2e-4
+GRAD_ABS_ESCAPE = 1e-5   # x max|reference|: tensors whose gradient is rounding noise around zero (max_abs <= 1e-7 + this * scale)
+LABEL_AMBIGUOUS_DISAGREE_MAX = 0.01   # of all rays: labels that differ where the top-2 margin is inside the logits' own fp32 noise
 
 
 def _dev():
@@ -152,8 +156,11 @@ def _compare_outputs(hip, ora, cfg):
             assert bool(same[sure].all()), "class argmax differs on rays with a clear margin"
             frac = float(sure.float().mean())
             assert frac >= 0.99 or sure.numel() < 200, ("margin-qualified fraction", frac)
+            n_dis = int((~same[~sure]).sum())
             LABEL_STATS.append({"rays": int(sure.numel()), "qualified": frac, "logit_err": lerr, "ambiguous": int((~sure).sum()),
-                                "ambiguous_disagree": int((~same[~sure]).sum())})
+                                "ambiguous_disagree": n_dis})
+            # ties inside fp32 noise cannot be matched bit for bit, but they are bounded: at most 1 % of the rays (one ray on tiny batches)
+            assert n_dis <= max(1, int(LABEL_AMBIGUOUS_DISAGREE_MAX * sure.numel())), ("ambiguous labels that disagree", n_dis, int(sure.numel()))
             continue
         err = max_abs(hip[k].detach().cpu(), v.detach())
         assert err <= OUT_TOL, (k, err)
@@ -222,7 +229,7 @@ def test_backward_matches_oracle_and_golden(name):
         assert g is not None, k
         err = rel_err(g.cpu(), ref)
         scale = float(np.abs(ref).max())
-        assert err <= GRAD_REL_TOL or max_abs(g.cpu(), ref) <= 1e-7 + 1e-3 * scale, (k, err, scale)
+        assert err <= GRAD_REL_TOL or max_abs(g.cpu(), ref) <= 1e-7 + GRAD_ABS_ESCAPE * scale, (k, err, scale)
         n += 1
     assert n >= 20
 
@@ -255,10 +262,19 @@ def test_full_width_forward_backward(name):
             g = grads[k[9:]]
             nrm = float(g.double().norm())
             ref = float(z[k])
-            assert abs(nrm - ref) <= 5e-3 * max(ref, 1e-9), (k, nrm, ref)
+            assert abs(nrm - ref) <= GRAD_REL_TOL * max(ref, 1e-9), (k, nrm, ref)
             s = g.detach().cpu().reshape(-1)[:: max(1, g.numel() // 64)][:64]
             rs = z["gradsample_" + k[9:]]
-            assert rel_err(s, rs) <= 1e-2 or max_abs(s, rs) <= 1e-3 * float(np.abs(rs).max() + 1e-12), k
+            assert rel_err(s, rs) <= 10 * GRAD_REL_TOL or max_abs(s, rs) <= GRAD_ABS_ESCAPE * float(np.abs(rs).max() + 1e-12), k
+    # the reference's FULL gradients of the first and the skip trunk layer, the sun head's first layer, the semantic head's last
+    # layer and the embedding (tools/gen_golden.py: FULL_GRADS_SEM), element for element
+    n_full = 0
+    for k in z.files:
+        if k.startswith("grad_"):
+            err = rel_err(grads[k[5:]].detach().cpu(), z[k])
+            assert err <= GRAD_REL_TOL, (k, err)
+            n_full += 1
+    assert n_full == (5 if name == "sem_siren_full" else 0)
 
 
 def test_inference_seam_explicit_xyz():
@@ -298,7 +314,7 @@ def test_ragged_and_multi_chunk_sizes():
         O.total_loss(O.training_losses(ora, b, cfg, 2)).backward()
         for k in po:
             err = rel_err(gp[k].grad.cpu(), po[k].grad)
-            assert err <= GRAD_REL_TOL or max_abs(gp[k].grad.cpu(), po[k].grad) <= 1e-7, (N, S, k, err)
+            assert err <= GRAD_REL_TOL or max_abs(gp[k].grad.cpu(), po[k].grad) <= 1e-7 + GRAD_ABS_ESCAPE * float(po[k].grad.abs().max()), (N, S, k, err)
         assert rel_err(emb_g.grad.cpu(), emb_o.grad) <= GRAD_REL_TOL
 
 

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT_TOL = 1e-4
 LOSS_RTOL = 2e-4
-GRAD_REL_TOL = 2e-3
+from tests.test_gpu_kernels import GRAD_REL_TOL, GRAD_ABS_ESCAPE   # 2e-4 / 1e-5: ten times the measured errors
 DEV = "cuda:0"
 
 
@@ -87,7 +87,7 @@ def test_training_step_matches_reference_fixture(name, monkeypatch):
         if k.startswith("grad_"):
             g, r = grads[k[5:]], z[k]
             g = torch.zeros(r.shape) if g is None else g.cpu()
-            assert rel_err(g, r) <= GRAD_REL_TOL or max_abs(g, r) <= 1e-7 + 1e-3 * float(np.abs(r).max()), (k, rel_err(g, r))
+            assert rel_err(g, r) <= GRAD_REL_TOL or max_abs(g, r) <= 1e-7 + GRAD_ABS_ESCAPE * float(np.abs(r).max()), (k, rel_err(g, r))
             n += 1
     assert n >= 20
 

@@ -10,13 +10,15 @@ operand-scaling checks it asked for:
        skipping and per-parameter step counts against torch.optim.Adam at the optimiser level
   tail heavy-tailed gradients (near-opaque rays next to thousands of almost-silent ones, far from 0.5 to 50)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import snerf_oracle as O
 from tests.helpers import load_fixture, fixture_batch, max_abs, rel_err, check_validation_metrics
-from tests.test_gpu_pipeline import _pipeline_for, _batch_to_dev, DEV, OUT_TOL, LOSS_RTOL, GRAD_REL_TOL
+from tests.test_gpu_pipeline import _pipeline_for, _batch_to_dev, DEV, OUT_TOL, LOSS_RTOL, GRAD_REL_TOL, GRAD_ABS_ESCAPE, ROOT
 
 pytestmark = pytest.mark.gpu
 ROW_TOL = 4e-6      # per-ray gradient rows down to 2^-20 of the loudest ray (test_heavy_tailed_gradients): measured 3.9e-7 with
@@ -68,7 +70,7 @@ def test_training_step_depth_branch_matches_reference_fixture(monkeypatch):
         if k.startswith("grad_"):
             g, r = grads[k[5:]], z[k]
             g = torch.zeros(r.shape) if g is None else g.cpu()
-            assert rel_err(g, r) <= GRAD_REL_TOL or max_abs(g, r) <= 1e-7 + 1e-3 * float(np.abs(r).max()), (k, rel_err(g, r))
+            assert rel_err(g, r) <= GRAD_REL_TOL or max_abs(g, r) <= 1e-7 + GRAD_ABS_ESCAPE * float(np.abs(r).max()), (k, rel_err(g, r))
             n += 1
     assert n >= 20
     # ds_noweights: every depth ray weighs 1 (training_step.py:40-44)
@@ -152,6 +154,63 @@ def test_batched_and_lean_inference_values_vs_oracle():
     lean = lean_inference(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, keys=keys, render_options=ro)
     for k in keys:
         assert torch.equal(lean[k], bi[k]), k
+
+
+_SHARD_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import torch, torch.distributed as dist
+from snerf_amd import parallel
+rank, world, dev = parallel.init_distributed(backend="gloo")
+from tests.test_gpu_rows import _frame_case
+from snerf_amd.eval.utils.util import sharded_lean_inference
+from snerf_amd.eval.extract_pointcloud import extract_pointcloud
+pipe, rays, extras, ro = _frame_case()
+res = sharded_lean_inference(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, keys=("rgb_coarse", "depth_coarse", "semantic_label_coarse", "weights_coarse"), render_options=ro)
+pc = extract_pointcloud(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, render_options=ro)
+lo, hi = res.pop("_rows")
+assert (lo, hi) == parallel.frame_shard(rays.shape[0]) and res["weights_coarse"].shape[0] == hi - lo
+torch.save({{"res": {{k: v.cpu() for k, v in res.items()}}, "rows": (lo, hi), "pc": {{k: v.cpu() for k, v in pc.items()}}}}, {out!r} + str(rank))
+dist.barrier()
+"""
+
+
+def _frame_case():
+    cfg = O.OracleCfg(fc_units=64, n_samples=24, render_chunk_size=100)
+    pipe, _ = _pipeline_for(cfg, 64, 5)
+    b = O.batch_to_torch(O.synthetic_batch(333, 24, seed=15))       # 333 rays over 2 ranks: 167 + 166, chunks of 100
+    return pipe, b["rays"].to(DEV), b["extras"].to(DEV), {"perturb_rand": b["u"].to(DEV)}
+
+
+def test_rank_sharded_full_frame_inference_equals_single_rank(tmp_path):
+    """SURVEY 8(e), last row: lean_inference / extract_pointcloud with the frame's rays sharded over 2 ranks (gloo, both on this
+    GPU): each rank renders its contiguous slice, rgb / depth / label are all-gathered -- the frame EVERY rank ends up with
+    equals the single-rank frame bit for bit; per-sample results stay local (this rank's rows)."""
+    import subprocess, sys
+    from snerf_amd.eval.utils.util import lean_inference
+    from snerf_amd.eval.extract_pointcloud import extract_pointcloud
+    pipe, rays, extras, ro = _frame_case()
+    keys = ("rgb_coarse", "depth_coarse", "semantic_label_coarse", "weights_coarse")
+    one = lean_inference(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, keys=keys, render_options=ro)
+    pc1 = extract_pointcloud(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, render_options=ro)
+    res = str(tmp_path / "shard.pt")
+    script = tmp_path / "worker.py"
+    script.write_text(_SHARD_WORKER.format(root=ROOT, out=res))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK="0"), cwd=ROOT) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    seen = 0
+    for r in range(2):
+        two = torch.load(res + str(r), weights_only=True)
+        lo, hi = two["rows"]
+        seen += hi - lo
+        for k in ("rgb_coarse", "depth_coarse", "semantic_label_coarse"):
+            assert torch.equal(two["res"][k], one[k].cpu()), (r, k)
+        assert torch.equal(two["res"]["weights_coarse"], one["weights_coarse"].cpu()[lo:hi])
+        for k, v in pc1.items():
+            assert torch.equal(two["pc"][k], v.cpu()), (r, k)
+    assert seen == rays.shape[0]
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -107,6 +107,23 @@ mine = bank.batch(3, 64, rank, world)["rays"]
 gathered = [torch.empty_like(mine) for _ in range(world)]
 dist.all_gather(gathered, mine)
 assert torch.equal(torch.cat(gathered, 0), bank.batch(3, 64)["rays"])
+# rank-sharded full-frame inference (SURVEY 8(e) last row): frame_shard + all_gather of the per-ray results, ragged tails and
+# an empty shard included; per-sample results stay local
+from snerf_amd.eval.utils.util import shard_and_gather
+for n in (1001, 64, 1):
+    def rows(lo, hi, n=n):
+        idx = torch.arange(lo, hi)
+        return {{"rgb_coarse": torch.stack([idx.float(), idx.float() * 2, idx.float() + 0.5], 1), "depth_coarse": idx.float() / 7,
+                "semantic_label_coarse": idx % 5, "weights_coarse": idx.float()[:, None].repeat(1, 4)}}
+    got = shard_and_gather(rows, n)
+    want = rows(0, n)
+    lo, hi = got["_rows"]
+    assert (lo, hi) == parallel.frame_shard(n) and hi - lo == max(0, min(-(-n // world), n - rank * -(-n // world)))
+    for k in ("rgb_coarse", "depth_coarse", "semantic_label_coarse"):
+        assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), (n, k)
+    assert torch.equal(got["weights_coarse"], want["weights_coarse"][lo:hi])
+assert [parallel.frame_shard(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+assert [parallel.frame_shard(2, r, 4) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
 dist.barrier()
 print("rank", rank, "ok")
 """

@@ -128,7 +128,7 @@ def losses_for_epoch(cfg, res, batch, epoch, depth_res=None):
 
 
 def make_case(name, cfg: O.OracleCfg, n_rays, seed, epoch, with_depth=False, store_params=True,
-              per_sample=True, grad_mode="full", adam_steps=0, mask_frac=None, car_prob=0.2):
+              per_sample=True, grad_mode="full", adam_steps=0, mask_frac=None, car_prob=0.2, full_grads=()):
     torch.manual_seed(0)
     cfgs, models, renderer, params = build_reference(cfg, seed)
     b = O.synthetic_batch(n_rays, cfg.n_samples, seed=seed + 100, n_classes=max(cfg.n_classes, 2), car_prob=car_prob)
@@ -172,6 +172,8 @@ def make_case(name, cfg: O.OracleCfg, n_rays, seed, epoch, with_depth=False, sto
         else:  # norms + a strided sample (full-width case: weights regenerate from the seed)
             fix[f"gradnorm_{k}"] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
             fix[f"gradsample_{k}"] = g.reshape(-1)[:: max(1, g.size // 64)][:64].copy()
+            if k in full_grads:   # the reference's FULL gradient of selected tensors (first / skip trunk layer, a head's first and last layer, the embedding)
+                fix[f"grad_{k}"] = g
     if store_params:
         for k, v in params.items():
             fix[f"param_{k}"] = v
@@ -229,6 +231,9 @@ def inference_case(name, cfg: O.OracleCfg, n_rays, seed):
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+FULL_GRADS_SEM = ("fc_net.0.weight", "fc_net.8.weight", "sun_v_net.0.weight", "semantic_prediction.2.weight", "model_t.weight")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     small = dict(fc_units=32, n_samples=16, render_chunk_size=200)  # chunk < P: exercises the chunk loop
@@ -253,7 +258,7 @@ def main():
               40, seed=7, epoch=0)
     # G: full width (W=512, S=64), few rays; weights regenerate from the seed
     make_case("sem_siren_full", O.OracleCfg(), 16, seed=8, epoch=2, store_params=False, per_sample=False,
-              grad_mode="sample")
+              grad_mode="sample", full_grads=FULL_GRADS_SEM)
     make_case("satnerf_full_c1", O.OracleCfg(model="satnerf", n_samples=32), 16, seed=9, epoch=2,
               store_params=False, per_sample=False, grad_mode="sample")
     # H: seam-3 inference on explicit xyz/z_vals
