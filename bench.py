@@ -39,6 +39,8 @@ warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does
 FLOPS_PER_SAMPLE_TRAIN = 31_453_696  # main 3*F_m + sc (F_s + 2*F_s-branch), fc_units=512
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
+HBM_ACHIEVABLE_BPS = 6.3e12          # same guide: achievable HBM3E streaming rate (peak 8 TB/s)
+ALGORITHMIC_BYTES_PER_RAY = 3700     # rays + targets in, per-ray results out, parameters amortised
 
 
 def make_cfgs(rays_per_gpu, samples, world, mfma="f16x2"):
@@ -142,9 +144,49 @@ def inference_rates(pipe, cfgs, device, samples, n_rays=40960 * 4):
             torch.cuda.empty_cache()
     finally:
         cfgs.pipeline.render_chunk_size = old
+    pi = os.path.join(ROOT, "profiles", "r04", "pmc_inference.json")
+    if os.path.isfile(pi) and samples == 64:
+        try:
+            pj = json.load(open(pi))
+            out["hbm_bytes_per_ray"] = pj["lean"]["hbm_bytes_per_ray"]
+            out["hbm_bytes_source"] = {"file": "profiles/r04/pmc_inference.json", "how": pj.get("how")}
+        except Exception:
+            pass
     out.update(unit="rays/s", rays=n_rays, samples=samples, render_chunk_size=40960,
                lean="rgb + depth + semantic_label, main pass only", batched="all results of render_rays incl. solar-correction pass")
     return out
+
+def reduced_precision_leg(rays, samples, device, steps=10, warmup=4):
+    """one training configuration in the REDUCED-precision mode (f16x1: one fp16 plane, one MFMA product): the reference's
+    `precision = 16` knob (baseline/pipelines/nerf.py:65), BASELINE.json configs[2] (S = 96, + L_t) and configs[4] (S = 128)"""
+    from snerf_amd import ops
+    from snerf_amd.framework.pipelines import load_pipeline, TrainLoop
+    ops.release_workspaces()
+    torch.cuda.empty_cache()
+    cfgs = make_cfgs(rays, samples, 1, "f16x1")
+    if samples == 96:
+        cfgs.pipeline.use_car_reg_loss = True     # configs[2]: semantic + transient regularisation L_t ...
+        cfgs.pipeline.car_reg_loss_start = 0      # ... active from the first epoch on (the bench never leaves epoch 0)
+    pipe = load_pipeline(cfgs)
+    pipe.log_metrics = False
+    loop = TrainLoop(pipe, cfgs, device)
+    step = 0
+    for _ in range(warmup):
+        out = loop.step(step); step += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = loop.step(step); step += 1
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    res = {"mode": "f16x1", "dtype": "f16 (one block-scaled fp16 plane; REDUCED)", "rays": rays, "samples": samples, "rays_per_s": rays / dt,
+           "ms_per_step": dt * 1e3, "steps": steps, "final_loss": float(out["loss"].detach()),
+           "config": "configs[2] shape (semantic + L_t)" if samples == 96 else "configs[4] per-GPU shape"}
+    del loop, pipe, out
+    ops.release_workspaces()
+    torch.cuda.empty_cache()
+    return res
+
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this script (one GPU per LOCAL_RANK,
@@ -245,9 +287,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-GEMM HIP-event timing")
     ap.add_argument("--serial-passes", action="store_true", help="run main and sc pass on one stream (as the roofline phase does)")
-    ap.add_argument("--mfma", default="f16x2", choices=["split3", "f16x2", "fp32", "split2", "bf16", "split3_bwd2"],
-                    help="matrix arithmetic: f16x2 (default, headline) and split3 are fp32-class; split2 / split3_bwd2 / bf16 are the REDUCED-precision "
-                         "modes of BASELINE configs[2]/[4] (reported under their own dtype, never as the fp32 headline)")
+    ap.add_argument("--mfma", default="f16x2", choices=["f16x2", "f16x1"],
+                    help="matrix arithmetic: f16x2 (default, headline: fp32-class); f16x1 = the REDUCED-precision mode of BASELINE configs[2]/[4] "
+                         "(one fp16 plane; reported under its own dtype, never as the fp32 headline)")
+    ap.add_argument("--no-reduced", action="store_true", help="skip the reduced-precision legs (4096 x 96 and 4096 x 128 in f16x1)")
     ap.add_argument("--no-eager-gpu-baseline", action="store_true", help="skip the stock-PyTorch-on-GPU denominator (3 steps)")
     ap.add_argument("--no-inference", action="store_true", help="skip the forward-only (full-frame inference) leg")
     ap.add_argument("--rehearsal", action="store_true", help="multi-rank protocol only (collectives, no kernels): CPU rigs")
@@ -368,7 +411,7 @@ def main():
     rays_total = args.rays * world * args.steps
     value = rays_total / dt
     flops_step_gpu = FLOPS_PER_SAMPLE_TRAIN * args.rays * args.samples
-    reduced = {"split3_bwd2": "f32 forward / REDUCED backward", "split2": "REDUCED (fp32 as two bf16, ~16 bits)", "bf16": "bf16 (REDUCED)"}
+    reduced = {"f16x1": "f16 (REDUCED: one block-scaled fp16 plane)"}
     line = {
         "metric": f"train rays/sec ({args.rays} rays x {args.samples} samples)", "value": value, "unit": "rays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "ms_per_step_median": median_ms,
@@ -376,14 +419,12 @@ def main():
         # BASELINE.md holds no published number for this metric (the reference publishes none): null by the contract.  The
         # north-star ratio against the reference's single-GPU PyTorch path measured in THIS run is `vs_reference_gpu_eager`.
         "vs_baseline": None,
-        "dtype": reduced.get(mode, {"f16x2": "f32(f16x2)", "split3": "f32(bf16x3)"}.get(mode, "f32")),   # fp32-class arithmetic on 16-bit matrix cores: see `arithmetic`
+        "dtype": reduced.get(mode, "f32(f16x2)"),   # fp32-class arithmetic on 16-bit matrix cores: see `arithmetic`
         "arithmetic": {
             "f16x2": "fp32-class: activations stored as two fp16 planes with one power-of-two exponent per 128 x 128 block (same bytes as "
                      "fp32), products hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate",
-            "split3": "fp32 storage and accumulate; products on bf16 MFMA via 3-plane splits, fp32-level accuracy",
-            "fp32": "v_mfma_f32_32x32x2_f32", "split2": "REDUCED: f32 storage/accumulate, operands as 2 bf16 planes (~16 bits, torch 'high')",
-            "bf16": "REDUCED: bf16 operands, f32 accumulate and storage (torch 'medium' / precision=16)",
-            "split3_bwd2": "f32 forward (3-plane splits, fp32-level results); REDUCED backward: 2 bf16 planes (~16 bits) in dX / dW"}[mode],
+            "f16x1": "REDUCED (the reference's precision = 16 runs): the same block-scaled tensors with ONE fp16 plane (11 significant bits, 2 bytes "
+                     "per element), one product per contraction step on v_mfma_f32_32x32x16_f16, fp32 accumulate"}[mode],
         "data": "synthetic",
         "config": {"workload": "JAX_068 semantic pipeline (configs[1]): RSSemanticNeRF fc_units=512 x 8 layers, C=5, "
                                f"{args.rays} rays x {args.samples} samples per GPU, fp32, main + solar-correction pass, "
@@ -406,21 +447,30 @@ def main():
                                                                                "includes waiting for the slowest rank's backward"}
     step_tflops = flops_step_gpu * args.steps / dt / 1e12  # per GPU, algorithmic (SURVEY 8d figure)
     if prof is not None:
-        x6 = mode != "fp32"
         # dominant kernel = variant 0: the K-contiguous dense-layer launches (forward X.W^T and dX), ~63 % of device time
         ms, fl, n = prof.ms[0], prof.flops[0], prof.launches[0]
         alg = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0          # algorithmic: 2 I J K per launch (SURVEY 8d's FLOPs)
-        mult, peak = ({"split3": 6.0, "f16x2": 3.0, "split2": 3.0, "bf16": 1.0, "split3_bwd2": 4.0}[mode], BF16_MFMA_PEAK_TFLOPS) if x6 else (1.0, FP32_MFMA_PEAK_TFLOPS)
+        mult, peak = {"f16x2": 3.0, "f16x1": 1.0}[mode], BF16_MFMA_PEAK_TFLOPS
         # HBM-side bytes per launch of the dominant kernel: NOT measured in this run (PMC passes need rocprofv3 runs of their own);
         # read from the newest committed PMC summary of this workload, with its provenance next to it
         traffic, traffic_source = None, None
-        for rr in ("r03", "r02"):
+        step_hbm, step_src = None, None
+        for rr in ("r04", "r03", "r02"):
             tf = os.path.join(ROOT, "profiles", rr, "pmc_hbm_traffic.json")
             if os.path.isfile(tf) and mode == "f16x2" and args.rays == 4096 and args.samples == 64:
                 try:
                     tj = json.load(open(tf))
                     traffic = tj.get("kc_bytes_per_launch")
                     traffic_source = {"file": f"profiles/{rr}/pmc_hbm_traffic.json", "commit": tj.get("commit"), "collected": tj.get("provenance", tj.get("note"))}
+                    # whole-step HBM bytes: every kernel's (read + written) x its launches per step, from the same PMC passes
+                    ks = tj.get("kernels", {}).get("bench step", {})
+                    nsteps = tj.get("bench_steps_profiled")
+                    if ks and not nsteps:      # older summaries: infer the profiled step count from the one-launch-per-step kernel
+                        nsteps = next((v["launches"] for k, v in ks.items() if k.startswith("adam_kernel")), None)
+                    if ks and nsteps:
+                        step_hbm = sum((v["read_bytes"] + v["written_bytes"]) * v["launches"] for v in ks.values()) / nsteps
+                        step_src = {"file": f"profiles/{rr}/pmc_hbm_traffic.json", "steps_profiled": nsteps,
+                                    "how": "sum over kernels of (FETCH_SIZE + WRITE_SIZE bytes per launch) x launches per step; counters calibrated on a known copy"}
                     break
                 except Exception:
                     traffic = None
@@ -429,11 +479,10 @@ def main():
             "frac": alg / peak,                              # ALGORITHMIC fraction: SURVEY 8(d) FLOPs / dense 16-bit MFMA peak
             "frac_mfma_issued": alg * mult / peak,           # matrix-pipe occupancy: `mult` 16-bit MFMA products per fp32 product
             "mfma_products_per_fp32_product": mult, "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": ("snerf::bsp::gemm_kc_kernel (persistent workgroups, two per CU, 128 x 256 tiles drawn from per-XCD counters; activations = "
-                       "fp16 planes by LDS-DMA, W = fragment-ordered planes straight from L2 as the MFMA A operand; 3 x v_mfma_f32_32x32x16_f16 "
-                       "per 32x32x16 block; one-pass sine epilogue on the accumulators, planes + block exponents out through LDS strips)" if mode == "f16x2" else
-                       ("snerf::gemm_x6_kernel<false,true,NP,128> (split-bf16 planes from fp32 storage)" if x6 else
-                        "snerf::gemm_kernel<128,128,64,64,false,false> (v_mfma_f32_32x32x2_f32)")),
+            "kernel": ("snerf::bsp::gemm_kc_kernel<PL> (persistent workgroups, two per CU, 128 x 256 tiles drawn from per-XCD counters; activations = "
+                       "fp16 planes by LDS-DMA, W = fragment-ordered planes straight from L2 as the MFMA A operand; "
+                       f"{int(mult)} x v_mfma_f32_32x32x16_f16 per 32x32x16 block; one-pass sine epilogue on the accumulators, planes + block "
+                       "exponents out through LDS strips)"),
             "vs_fp32_mfma_peak": alg / FP32_MFMA_PEAK_TFLOPS,
             "launches": int(n), "avg_launch_ms": ms / max(n, 1),
             "measured_over": f"{prof_steps} extra steps after the timed region, main and sc pass serialised (SNERF_OVERLAP_SC=0 behaviour), "
@@ -443,6 +492,13 @@ def main():
                 "algorithmic_tflops": (prof.flops[v] / (prof.ms[v] * 1e-3) / 1e12) if prof.ms[v] > 0 else 0.0}
                 for v in range(4) if prof.launches[v] > 0},
             "whole_step_algorithmic_tflops": step_tflops, "whole_step_frac": step_tflops / peak,
+            # the whole step's memory account next to the matrix one: HBM bytes per step (PMC, committed summary) and the time
+            # they take at the guide's achievable HBM rate -- the stored-activation, layer-per-launch design sits between this
+            # floor and the three-product matrix floor at the same time
+            "step_hbm_bytes": step_hbm, "step_hbm_source": step_src,
+            "step_hbm_floor_ms": (step_hbm / HBM_ACHIEVABLE_BPS * 1e3) if step_hbm else None,
+            "step_algorithmic_hbm_bytes": ALGORITHMIC_BYTES_PER_RAY * args.rays,
+            "step_mfma_floor_ms": flops_step_gpu * mult / (peak * 1e12) * 1e3,
         }
     else:
         line["roofline"] = {"bound": "mfma", "achieved": step_tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -450,10 +506,18 @@ def main():
                             "kernel": "whole step (algorithmic FLOPs / wall time); per-kernel timing disabled"}
     if world == 1 and not args.no_inference:
         line["inference"] = inference_rates(pipe, cfgs, device, args.samples)
+    if world == 1 and not args.no_reduced and mode == "f16x2":
+        # BASELINE configs[2] / [4] name reduced precision (the reference's `precision = 16`): the same step in the one-plane mode at
+        # their per-GPU shapes.  Reported here, never in `value`.
+        del loop, pipe
+        line["reduced_precision"] = [reduced_precision_leg(4096, S, device) for S in (96, 128)]
+        loop = pipe = None
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.samples)
     if world == 1 and not args.no_eager_gpu_baseline:
-        del loop, pipe
+        loop = pipe = None
+        from snerf_amd import ops as _ops
+        _ops.release_workspaces()
         torch.cuda.empty_cache()
         line["reference_gpu_eager"] = eager_gpu_baseline(args.rays, args.samples, device)
         line["vs_reference_gpu_eager"] = value / line["reference_gpu_eager"]["value"]

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNERF_ABI_VERSION 2
+#define SNERF_ABI_VERSION 3
 #define SNERF_MAX_LAYERS 16
 
 /* error codes */
@@ -46,24 +46,19 @@ extern "C" {
                                  (semantic/components/rendering.py:59-78) */
 
 /* Arithmetic of the dense contractions.  With NONE of the arithmetic bits set a pass runs the default, SNERF_FLAG_F16X2
- * (the same for C and Python callers); the other bits select the alternatives and exclude each other. */
+ * (the same for C and Python callers); the two bits exclude each other. */
 #define SNERF_FLAG_F16X2 64u   /* DEFAULT (flags = 0 means this): fp32-class arithmetic on the fp16 matrix cores.  Every activation
                                   tensor of the workspace is two fp16 planes (22 significant bits) with one power-of-two exponent
                                   per 128 x 128 block, written once by the producing kernel; a product is hi*hi + hi*lo + lo*hi on
                                   v_mfma_f32_32x32x16_f16 with fp32 accumulation; the dropped lo*lo term is 2^-22 relative, below
                                   an fp32 GEMM's own rounding (normwise).  Needs fc_units % 32 == 0, feat_last % 16 == 0 and
                                   3 + t_dim (x2 with a separate t_s) <= 16: other shapes return SNERF_ERR_BAD_DESC */
-#define SNERF_FLAG_SPLIT3 128u /* fp32-class, conservative: three bf16 planes per fp32 operand (24 significant bits whatever the
-                                  magnitude), six v_mfma_f32_32x32x16_bf16 products, fp32 accumulate; twice the matrix work of
-                                  the default */
-#define SNERF_FLAG_FP32_MFMA 4u /* contract on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32): exact fp32 products at 1/16
-                                  of the 16-bit matrix rate (diagnostics) */
-#define SNERF_FLAG_BF16 8u     /* REDUCED precision (the reference's `precision = 16` runs; BASELINE.json configs[2], [4]):
-                                  operands rounded to one bf16 plane, one MFMA product, fp32 accumulate, fp32 storage.
-                                  Judged on PSNR / mIoU, not on the 1e-4 parity bar. */
-#define SNERF_FLAG_BF16X3 16u  /* REDUCED precision: two bf16 planes (hi | mid), products hh + hm + mh: ~16 significant bits */
-#define SNERF_FLAG_BWD_BF16X3 32u /* SNERF_FLAG_SPLIT3 forward (the 1e-4 output bar) and REDUCED precision in snerf_backward only:
-                                   the dX / dW contractions use two bf16 planes (gradients ~1e-4 relative) */
+#define SNERF_FLAG_F16X1 8u    /* REDUCED precision (the reference's `precision = 16` runs, baseline/pipelines/nerf.py:65; BASELINE.json
+                                  configs[2], [4]): the same block-scaled tensors with ONE fp16 plane -- 11 significant bits relative
+                                  to the block's maximum, 2 bytes per element -- weights packed as one plane, one MFMA product per
+                                  contraction step (a third of the default's matrix work, half its operand bytes), fp32 accumulate.
+                                  Same kernels, templated on the plane count.  Judged on PSNR / mIoU, not on the 1e-4 parity bar.
+                                  Needs fc_units % 64 == 0 and feat_last % 32 == 0 on top of the default's shape rules */
 
 /* Model + batch description.  Field names follow the reference config
  * (configs/pipelines/rs_semantic.toml:13-67, semantic/pipelines/rs_semantic.py:125-141). */
@@ -162,9 +157,8 @@ size_t snerf_workspace_bytes(const SnerfDesc* desc);
 /* ---- parameter packing ------------------------------------------------------------------------- */
 /* Gather the state_dict tensors into the padded, MFMA-friendly packed layout (DESIGN.md "Data layout").
  * Replaces nothing in the reference (torch.nn.Linear owns its layout there); run once per optimiser step.
- * The pre-split weight operands inside the buffer follow desc->flags' arithmetic (k-tile-major bf16 planes under the
- * arithmetic flags; fragment-ordered fp16 planes + one exponent per matrix in the default arithmetic): pack, forward and
- * backward must use the same arithmetic flags. */
+ * The weight operands inside the buffer follow desc->flags' arithmetic (fragment-ordered fp16 planes + one exponent per matrix:
+ * two planes in the default arithmetic, one under SNERF_FLAG_F16X1): pack, forward and backward must use the same arithmetic flag. */
 int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* packed, void* stream);
 /* Scatter packed gradients back into tensors shaped like the parameters (overwrite, or add if accumulate). */
 int snerf_unpack_grads(const SnerfDesc* desc, const float* packed_grads, const SnerfParams* grads,
@@ -271,9 +265,8 @@ int snerf_adam_step(float* params, const float* grads, float* exp_avg, float* ex
  * Between snerf_profile_begin and snerf_profile_end every GEMM launch is bracketed by HIP events on the
  * stream it is launched on; _end synchronises those events and returns, per kernel variant, the summed
  * device time, the algorithmic FLOPs (2*I*J*K of each launch) and the launch count.
- * variant 0: K-contiguous GEMMs (forward X.W^T and dX = dZ.(W^T)^T): gemm_kc_kernel of bsp_gemm.hip in the default
- *            arithmetic (128x256 tile); the 128x128 tile of gemm_x6_kernel / gemm_kernel under the arithmetic flags,
- *         1: mixed layouts (unused since dX reads a transposed copy of W),
+ * variant 0: K-contiguous GEMMs (forward X.W^T and dX = dZ.(W^T)^T): gemm_kc_kernel of bsp_kc.hip (128x256 tile),
+ *         1: unused,
  *         2: dW = dZ^T.X (both operands read along the points, split over the points): gemm_dw_kernel (256x256 tile),
  *         3: the 32-wide head variants (gemm_kcn_kernel, gemm_dw_kernel<32>). */
 #define SNERF_PROFILE_VARIANTS 4
@@ -285,20 +278,15 @@ typedef struct SnerfProfile {
 int snerf_profile_begin(void);
 int snerf_profile_end(SnerfProfile* out);
 
-/* ---- test hook: the tiled fp32-MFMA GEMM used by every layer --------------------------------------
- * C[I,J] = sum_k A(i,k) * B(j,k);  a_ic/b_ic = 0: operand stored (rows, K) K-contiguous,
- * 1: stored (K, rows) row-contiguous.  Exposed so tests can check the MFMA tiling in isolation. */
-int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, int b_ic,
-                    float* C, int ldc, int I, int J, int K, int narrow, void* stream);
-/* test hooks of the block-scaled fp16-plane kernels (csrc/bsp.h): fp32 in / fp32 out around one launch; synchronous and
- * allocating -- tests only */
+/* test hooks of the block-scaled fp16-plane kernels (csrc/bsp.h): fp32 in / fp32 out around one launch; `planes` = 2 (default
+ * arithmetic) or 1 (SNERF_FLAG_F16X1); synchronous and allocating -- tests only */
 int snerf_test_set_kc_grid(int n_workgroups);   /* persistent grid of the K-contiguous launches (0: two per CU): forces the tile loop at test sizes */
-int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int col0, float* dst, int* exps_out, void* stream);
+int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int col0, float* dst, int* exps_out, int planes, void* stream);
 int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, const float* bias, int I, int J, int K, int a_col0,
                       int c_col0, int act, float w0, int aux_mode, const float* Hact, const unsigned* Hsign, float* C,
-                      unsigned* Csign, float* colsum, int narrow, void* stream);
+                      unsigned* Csign, float* colsum, int narrow, int planes, void* stream);
 int snerf_test_bsp_dw(const float* A, int lda_src, const float* B, int ldb_src, int P, int I, int J, int a_col0, int b_col0,
-                      int k_split, int narrow_i, float* C, void* stream);
+                      int k_split, int narrow_i, float* C, int planes, void* stream);
 
 #ifdef __cplusplus
 }

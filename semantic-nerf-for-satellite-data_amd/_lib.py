@@ -6,20 +6,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SNERF_LIB_PATH: an alternative build of the library (ablation harness of tools/ablate; diagnostics only)
 LIB_PATH = os.environ.get("SNERF_LIB_PATH") or os.path.join(_HERE, "libsnerf_hip.so")
 MAX_LAYERS = 16
-ABI_VERSION = 2   # include/snerf_hip.h SNERF_ABI_VERSION
+ABI_VERSION = 3   # include/snerf_hip.h SNERF_ABI_VERSION
 
 FLAG_TRAIN = 1
 FLAG_SC_PASS = 2
 # arithmetic bits of SnerfDesc.flags (include/snerf_hip.h): none set = the default, f16x2
-FLAG_F16X2 = 64       # default: fp32-class on the fp16 matrix cores, two fp16 planes of power-of-two-scaled operands
-FLAG_SPLIT3 = 128     # fp32-class, three bf16 planes / six products
-FLAG_FP32_MFMA = 4    # v_mfma_f32_32x32x2_f32 (diagnostics)
-FLAG_BF16 = 8         # reduced precision: one bf16 plane per operand (precision = 16 / float32_matmul_precision "medium")
-FLAG_BF16X3 = 16      # reduced precision: two bf16 planes, three products (float32_matmul_precision "high")
-FLAG_BWD_BF16X3 = 32  # split3 forward, reduced precision (two planes) in the backward contractions only
-# ModelSpec.mfma -> SnerfDesc.flags
-MFMA_FLAGS = {"f16x2": 0, "split3": FLAG_SPLIT3, "fp32": FLAG_FP32_MFMA, "split2": FLAG_BF16X3, "bf16": FLAG_BF16,
-              "split3_bwd2": FLAG_BWD_BF16X3}
+FLAG_F16X2 = 64       # default: fp32-class on the fp16 matrix cores, two fp16 planes of power-of-two-scaled operands, three products
+FLAG_F16X1 = 8        # reduced precision: ONE fp16 plane of the same block-scaled tensors, one product (precision = 16 / "medium" / "high")
+# ModelSpec.mfma -> SnerfDesc.flags ("bf16" = the name BASELINE.json's configs use for the reduced-precision runs: same mode)
+MFMA_FLAGS = {"f16x2": 0, "f16x1": FLAG_F16X1, "bf16": FLAG_F16X1}
 
 _fp = C.POINTER(C.c_float)
 
@@ -130,20 +125,17 @@ def lib():
     L.snerf_backward.restype = C.c_int
     L.snerf_backward.argtypes = [C.POINTER(SnerfDesc), C.c_void_p, C.POINTER(SnerfInputs), C.POINTER(SnerfOutGrads),
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-    L.snerf_test_gemm.restype = C.c_int
-    L.snerf_test_gemm.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
-                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.snerf_test_set_kc_grid.restype = C.c_int
     L.snerf_test_set_kc_grid.argtypes = [C.c_int]
     L.snerf_test_bsp_roundtrip.restype = C.c_int
-    L.snerf_test_bsp_roundtrip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.snerf_test_bsp_roundtrip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.snerf_test_bsp_kc.restype = C.c_int
     L.snerf_test_bsp_kc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p, C.c_int, C.c_void_p]
+                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.snerf_test_bsp_dw.restype = C.c_int
     L.snerf_test_bsp_dw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                    C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+                                    C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.snerf_loss_workspace_bytes.restype = C.c_size_t
     L.snerf_loss_workspace_bytes.argtypes = [C.POINTER(SnerfLossCfg)]
     L.snerf_loss_partial.restype = C.c_int
@@ -176,7 +168,7 @@ def check(rc, what):
 
 
 EXPORTED_SYMBOLS = ("snerf_version", "snerf_last_error", "snerf_packed_floats", "snerf_grad_floats", "snerf_workspace_bytes",
-                    "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward", "snerf_test_gemm",
+                    "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward",
                     "snerf_loss_workspace_bytes", "snerf_loss_partial", "snerf_loss_finish", "snerf_profile_begin",
                     "snerf_profile_end", "snerf_sample_z", "snerf_adam_step", "snerf_test_bsp_roundtrip", "snerf_test_bsp_kc",
                     "snerf_test_bsp_dw", "snerf_test_set_kc_grid", "snerf_embedding_rows", "snerf_embedding_backward")

@@ -17,7 +17,7 @@ from .base_ray_pipeline import BaseRayPipeline
 class NeRFConfig(BaseModel):
     pipeline: Optional[str] = None
     precision: int = 32
-    mfma_precision: Literal["split3", "f16x2", "fp32", "split2", "bf16", "split3_bwd2", "auto"] = "f16x2"  # build extension: ops.mfma_mode
+    mfma_precision: Literal["f16x2", "f16x1", "bf16", "auto"] = "f16x2"  # build extension: ops.mfma_mode
     use_utm_coordinate_system: Union[bool, int] = False
     version: int = 1
     n_samples: int = 64

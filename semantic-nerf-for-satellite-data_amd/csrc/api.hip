@@ -29,23 +29,6 @@ void set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------------
 // plan
 // ---------------------------------------------------------------------------------------------------
-// split-K choice for one dW matrix: tiles x splits ~ one full round of 256 CUs x 4 resident workgroups,
-// at least 512 contraction rows per split, at most 256 splits.  All GEMMs that fill one matrix
-// (e.g. the [gamma | h] column segments of a skip layer) share the choice made for the widest of them.
-DwSplit dw_choose(int P, int rows, int cols, bool narrow_rows) {
-  // whole 128-row blocks only: a 32-row tail (the sigma rows riding on a trunk matrix) is its own narrow launch
-  const int tiles = (narrow_rows || rows < 128 ? 1 : rows / 128) * ((cols + 127) / 128);
-  int ns = (1024 + tiles / 2) / tiles;
-  const int ns_max = P / 512 > 1 ? P / 512 : 1;
-  if (ns > ns_max) ns = ns_max;
-  if (ns > 256) ns = 256;
-  if (ns < 1) ns = 1;
-  DwSplit d;
-  d.k_split = round_up((P + ns - 1) / ns, 32);
-  d.ns = (P + d.k_split - 1) / d.k_split;
-  return d;
-}
-
 // split-K choice for the plane dW kernel: 256 x 256 tiles, one workgroup per CU -> tiles x splits ~ 256 (ONE round of
 // the chip: every workgroup writes a 256 KB slab, so the slab traffic of a launch is 64 MB however the matrix is shaped;
 // two rounds doubled it and the reduction that follows), splits of whole 128-point exponent blocks, <= 16384 points each
@@ -62,14 +45,14 @@ DwSplit dw_choose_bsp(int P, int rows, int cols, bool narrow_rows) {
   return d;
 }
 
-// ---- block-scaled plane layout (fmt 1): weight operand packs + workspace -------------------------------------------
+// ---- block-scaled plane layout: weight operand packs + workspace -------------------------------------------
 static void plan_bsp(Plan& p) {
   // weight operands: every K-contiguous GEMM's B, as a WF16 pack behind the fp32 region (csrc/bsp.h)
   size_t off = 0;
   int n = 0, ne = 0;
   auto job = [&](int rows, int K, int e) {
     p.wj_off[n] = off; p.wj_rows[n] = rows; p.wj_K[n] = K; p.wj_e[n] = e;
-    off += bsp::wp16_bytes(rows, K);
+    off += bsp::wp16_bytes(rows, K, p.pl);
     return n++;
   };
   for (int i = 0; i < p.L; ++i) {
@@ -87,16 +70,15 @@ static void plan_bsp(Plan& p) {
   p.wp_bytes = round_up_sz(off, 256);
   p.packed_floats = p.n_fp32 + (p.wp_bytes + 2 * Plan::WJ_MAX * 4 + 256) / 4;
 
-  // workspace: activations as planes (4 bytes per element, like fp32) + exponent tables + sign words
+  // workspace: activations as planes (4 bytes per element, like fp32; 2 with one plane) + exponent tables + sign words
   size_t wo = 0;
   auto wtake = [&](size_t bytes) { size_t o = wo; wo += round_up_sz(bytes, 256); return o; };
   const size_t Pp = p.Pp;
-  auto planes = [&](int ld) { return wtake(bsp::plane_bytes(Pp, ld)); };
+  auto planes = [&](int ld) { return wtake(bsp::plane_bytes(Pp, ld, p.pl)); };
   auto etab = [&](int ld) { return wtake(bsp::etab_ints(Pp, ld) * 4); };
   auto signs = [&](int ld) { return wtake(bsp::sign_words(Pp, ld) * 4); };
   const bool keep_c = p.train && p.siren;
   p.h1w = p.sc ? p.H : p.N1;
-  p.sign_deriv = true;
   p.o_z = wtake(((size_t)p.P + 4) * 4);
   p.o_T = wtake((size_t)p.P * 4);
   p.o_rgbraw = wtake((size_t)p.N * 3 * 4);
@@ -148,19 +130,15 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   if (d->skip_mask & 1u) return bad("layer 0 cannot be a skip layer");
   p.N = d->n_rays; p.S = d->n_samples; p.P = p.N * p.S; p.Pp = round_up(p.P, 128);
   p.W = d->fc_units; p.H = d->feat_last; p.L = d->fc_layers; p.F = d->n_freq;
-  p.E = p.F > 0 ? 6 * p.F : 3; p.Ep = round_up(p.E, 32);  // LDS stages (32 k) never straddle the [gamma | h] segments
+  {  // arithmetic: none of the bits = the default (SNERF_FLAG_F16X2), for C and Python callers alike
+    const unsigned sel = d->flags & (SNERF_FLAG_F16X2 | SNERF_FLAG_F16X1);
+    if (sel == (SNERF_FLAG_F16X2 | SNERF_FLAG_F16X1)) return bad("more than one arithmetic flag (SNERF_FLAG_F16X2 / SNERF_FLAG_F16X1)");
+    p.pl = (sel & SNERF_FLAG_F16X1) ? 1 : 2;
+  }
+  p.E = p.F > 0 ? 6 * p.F : 3; p.Ep = round_up(p.E, p.pl == 2 ? 32 : 64);  // LDS stages (128 bytes per row: 32 / 64 k) never straddle the [gamma | h] segments
   p.tau = d->t_dim; p.C = d->n_classes;
   p.siren = d->siren != 0; p.sem_sigmoid = d->sem_sigmoid != 0;
   p.train = (d->flags & SNERF_FLAG_TRAIN) != 0; p.sc = (d->flags & SNERF_FLAG_SC_PASS) != 0;
-  {  // arithmetic: at most one of the selecting bits; none = the default (SNERF_FLAG_F16X2), for C and Python callers alike
-    const unsigned sel = d->flags & (SNERF_FLAG_F16X2 | SNERF_FLAG_SPLIT3 | SNERF_FLAG_FP32_MFMA | SNERF_FLAG_BF16 |
-                                     SNERF_FLAG_BF16X3 | SNERF_FLAG_BWD_BF16X3);
-    const bool bwd2_on_split3 = sel == (SNERF_FLAG_SPLIT3 | SNERF_FLAG_BWD_BF16X3);   // the second implies the first
-    if ((sel & (sel - 1)) != 0 && !bwd2_on_split3) return bad("more than one arithmetic flag (SNERF_FLAG_F16X2 / SPLIT3 / FP32_MFMA / BF16 / BF16X3 / BWD_BF16X3)");
-    p.x6 = (sel & SNERF_FLAG_FP32_MFMA) == 0;
-    p.planes = (sel & SNERF_FLAG_BF16) ? 1 : ((sel & SNERF_FLAG_BF16X3) ? 2 : 3);
-    if (sel == 0 || sel == SNERF_FLAG_F16X2) { p.fmt = 1; p.planes = 2; }
-  }
   p.skip_mask = d->skip_mask;
   const bool sem = p.C > 0;
   const bool sbeta = sem && d->use_separate_beta_for_s;
@@ -171,8 +149,9 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.sbeta_ts = sbeta && sep_ts;
   p.x_sun = 0; p.x_t = 3; p.x_ts = sep_ts ? 3 + p.tau : -1;
   p.Xp = round_up(3 + p.tau + (sep_ts ? p.tau : 0), 16);  // FA % 16 == 0: weight planes are stored in 16-k tiles
-  if (p.fmt == 1 && ((p.H & 15) || (p.W & 31) || p.Xp != 16)) return bad("the default arithmetic needs feat % 32 == 0, feat_last % 16 == 0 and 3 + t_dim (x2 with separate t_s) <= 16; use SNERF_FLAG_SPLIT3");
-  p.Wf = p.fmt == 1 ? round_up(p.W, 128) : p.W;         // extras block on an exponent-block boundary
+  if ((p.H & 15) || (p.W & 31) || p.Xp != 16) return bad("fc_units % 32 == 0, feat_last % 16 == 0 and 3 + t_dim (x2 with separate t_s) <= 16 are required");
+  if (p.pl == 1 && ((p.W & 63) || (p.H & 31))) return bad("SNERF_FLAG_F16X1 needs fc_units % 64 == 0 and feat_last % 32 == 0 (LDS stages of 64 columns)");
+  p.Wf = round_up(p.W, 128);         // extras block on an exponent-block boundary
   p.FA = p.Wf + p.Xp;
   int nb = 0;
   p.blk_rgb = nb++;
@@ -182,7 +161,7 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.blk_sun = nb++;
   p.nblk = nb;
   p.KF = (nb - 1) * p.H;
-  if (p.fmt == 1) p.KF = round_up(p.KF, 128);           // sun block on an exponent-block boundary (pad rows / columns are zero)
+  p.KF = round_up(p.KF, 128);           // sun block on an exponent-block boundary (pad rows / columns are zero)
   p.sun_col = p.KF;
   p.N1 = p.KF + p.H;
 
@@ -201,72 +180,8 @@ int make_plan(const SnerfDesc* d, Plan* pl) {
   p.w_fin = take((size_t)NARROW * p.KF); p.b_fin = take(NARROW);
   p.sky_floats = 9 * p.H + 4;
   p.sky = take(p.sky_floats);
-  for (int i = 1; i < p.L; ++i) p.t_tr[i] = take((size_t)p.W * p.W);
-  p.t_fs = take((size_t)p.W * (p.W + NARROW));
-  p.t_h1 = take((size_t)p.FA * p.N1);
-  p.t_s2 = take((size_t)p.H * p.H); p.t_s3 = take((size_t)p.H * p.H);
-  p.t_s4 = take((size_t)p.H * NARROW);
-  p.t_fin = take((size_t)p.KF * NARROW);
   p.n_fp32 = off;
-  p.packed_floats = off + round_up_sz((3 * off + 1) / 2, 64);
-
-  // ---- workspace
-  size_t wo = 0;
-  auto wtake = [&](size_t floats) { size_t o = wo; wo += round_up_sz(floats * sizeof(float), 256); return o; };
-  const size_t Pp = p.Pp;
-  p.h1w = p.sc ? p.H : p.N1;
-  p.o_z = wtake((size_t)p.P + 4);
-  p.o_T = wtake(p.P);
-  p.o_rgbraw = wtake((size_t)p.N * 3);
-  p.o_pe = wtake(Pp * p.Ep);
-  const bool keep_c = p.train && p.siren;
-  static const bool float_deriv = getenv("SNERF_DERIV") && !strcmp(getenv("SNERF_DERIV"), "float");  // diagnostics: A/B
-  p.sign_deriv = !float_deriv;
-  auto dsize = [&](int ld) { return p.sign_deriv ? sign_floats(Pp, ld) : Pp * (size_t)ld; };
-  if (p.train) {
-    for (int i = 0; i < p.L; ++i) p.o_h[i] = wtake(Pp * p.W);
-    for (int i = 0; i < p.L; ++i) p.o_c[i] = keep_c ? wtake(dsize(p.W)) : 0;  // sign words of cos, 1 bit / element
-  } else {
-    const size_t a = wtake(Pp * p.W), b = wtake(Pp * p.W);
-    for (int i = 0; i < p.L; ++i) { p.o_h[i] = (i & 1) ? b : a; p.o_c[i] = 0; }
-  }
-  p.o_fa = wtake(Pp * p.FA);
-  p.o_h1 = wtake(Pp * p.h1w);
-  p.o_c1 = keep_c ? wtake(dsize(p.h1w)) : 0;
-  p.o_s2 = wtake(Pp * p.H); p.o_s3 = wtake(Pp * p.H);
-  p.o_cs2 = keep_c ? wtake(dsize(p.H)) : 0; p.o_cs3 = keep_c ? wtake(dsize(p.H)) : 0;
-  p.o_sigo = wtake(Pp * NARROW); p.o_fino = wtake(Pp * NARROW); p.o_suno = wtake(Pp * NARROW);
-  p.maxw = p.W > p.FA ? p.W : p.FA;
-  if (p.h1w > p.maxw) p.maxw = p.h1w;
-  p.nrb = (p.P + 31) / 32;
-  p.comp_blocks = composite_bwd_blocks(p.N);
-  if (p.train) {
-    p.o_dza = wtake(Pp * p.maxw); p.o_dzb = wtake(Pp * p.maxw);
-    p.o_dsa = wtake(Pp * p.H); p.o_dsb = wtake(Pp * p.H);
-    p.o_dsig = wtake(Pp * NARROW); p.o_dfin = wtake(Pp * NARROW); p.o_dsun = wtake(Pp * NARROW);
-    p.o_colsum = wtake((size_t)p.nrb * p.maxw);
-    p.o_colsum2 = wtake((size_t)64 * (p.maxw > p.sky_floats ? p.maxw : p.sky_floats));
-    // dW split-K slabs: every matrix picks its own split count (dw_choose) so that tiles x splits fills
-    // the chip; capacity = the largest (matrix floats x splits) over all matrices of this pass
-    auto need = [&](int rows, int ld, int cols, bool narrow) {
-      const DwSplit d = dw_choose(p.P, rows, cols, narrow);
-      return round_up_sz((size_t)rows * ld, 64) * d.ns;
-    };
-    size_t cap = need(p.h1w, p.FA, p.FA, false);
-    for (int i = 0; i < p.L; ++i) { const size_t c = need(p.W, p.k_tr[i], p.W, false); if (c > cap) cap = c; }
-    size_t c2 = need(p.W + NARROW, p.W, p.W, false); if (c2 > cap) cap = c2;
-    c2 = need(NARROW, p.KF, p.KF, true); if (c2 > cap) cap = c2;
-    c2 = need(NARROW, p.H, p.H, true); if (c2 > cap) cap = c2;
-    c2 = need(p.H, p.H, p.H, false); if (c2 > cap) cap = c2;
-    p.slab_floats = cap;
-    p.o_slab = wtake(p.slab_floats);
-    { size_t big = (size_t)p.N1 * p.FA; for (int i = 0; i < p.L; ++i) if ((size_t)p.W * p.k_tr[i] > big) big = (size_t)p.W * p.k_tr[i];
-      if ((size_t)(p.W + NARROW) * p.W > big) big = (size_t)(p.W + NARROW) * p.W; if ((size_t)NARROW * p.KF > big) big = (size_t)NARROW * p.KF;
-      p.o_slab2 = wtake(64 * round_up_sz(big, 64)); }
-    p.o_skyslab = wtake((size_t)p.comp_blocks * 4 * p.sky_floats);
-  }
-  p.ws_bytes = wo;
-  if (p.fmt == 1) plan_bsp(p);
+  plan_bsp(p);
   return SNERF_OK;
 }
 
@@ -334,292 +249,7 @@ static void build_tables(const Plan& p, const SnerfParams* w, TableBuilder& tb) 
   tb.add(w->sky_b2, 3, 1, 3, p.sky + 9 * (size_t)H, 3);
 }
 
-// ---------------------------------------------------------------------------------------------------
-// forward
-// ---------------------------------------------------------------------------------------------------
-struct WS {
-  char* base;
-  float* f(size_t off) const { return reinterpret_cast<float*>(base + off); }
-  unsigned* u(size_t off) const { return reinterpret_cast<unsigned*>(base + off); }
-};
-
 #define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
-
-// Weight operand of a K-contiguous GEMM: B = rows [row0, ...) and k >= k0 of the packed matrix at float offset `mat`
-// ([rows][ld]); attach the matrix's pre-split, k-tile-major bf16 planes (same element range in the plane region).
-
-static inline void weights(GemmArgs& g, const Plan& p, const float* pk, size_t mat, int rows, int ld, int row0 = 0, int k0 = 0) {
-  g.B = pk + mat + (size_t)row0 * ld + k0; g.ldb = ld;
-  g.x6 = p.x6; g.planes = p.planes;
-  if (p.x6) {
-    g.Bpl = reinterpret_cast<const unsigned short*>(pk + p.n_fp32) + mat; g.pl_stride = p.n_fp32;
-    g.bt_rows = rows; g.bt_row0 = row0; g.bt_k0 = k0; g.bt_elems = (size_t)rows * ld;
-  }
-}
-
-static int forward_impl(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutputs* out, WS ws,
-                        hipStream_t st) {
-  const int P = p.P, W = p.W, H = p.H;
-  float* z = ws.f(p.o_z);
-  // 1. depths
-  if (in->z_vals) {
-    SNERF_HIP_CHECK(hipMemcpyAsync(z, in->z_vals, sizeof(float) * P, hipMemcpyDeviceToDevice, st));
-  } else {
-    RC(launch_sample_z(in->rays, in->z_steps, in->u, z, p.N, p.S, st));
-  }
-  if (out->z_vals) SNERF_HIP_CHECK(hipMemcpyAsync(out->z_vals, z, sizeof(float) * P, hipMemcpyDeviceToDevice, st));
-  // 2. positions + encoding + extras
-  EncodeArgs ea;
-  ea.rays = in->xyz ? nullptr : in->rays; ea.xyz = in->xyz; ea.z = z;
-  ea.sun_d = in->sun_d; ea.sun_stride = in->sun_stride; ea.t = in->t; ea.t_s = in->t_s;
-  ea.dir_is_sun = (p.sc && !in->xyz) ? 1 : 0;
-  ea.N = p.N; ea.S = p.S; ea.F = p.F; ea.Ep = p.Ep; ea.pe = ws.f(p.o_pe);
-  ea.fa = ws.f(p.o_fa); ea.FA = p.FA; ea.W = p.Wf; ea.Xp = p.Xp; ea.x_sun = p.x_sun; ea.x_t = p.x_t; ea.x_ts = p.x_ts; ea.tau = p.tau;
-  RC(launch_encode(ea, st));
-  // 3. trunk (rs_semantic.py:325-334)
-  const int act = p.siren ? ACT_SIN : ACT_RELU;
-  for (int i = 0; i < p.L; ++i) {
-    GemmArgs g;
-    const bool skip = (p.skip_mask >> i) & 1u;
-    if (i == 0) { g.A = ws.f(p.o_pe); g.lda = p.Ep; }
-    else if (skip) { g.A = ws.f(p.o_pe); g.lda = p.Ep; g.Ka = p.Ep; g.A2 = ws.f(p.o_h[i - 1]); g.lda2 = W;
-                     }
-    else { g.A = ws.f(p.o_h[i - 1]); g.lda = W; }
-   
-    weights(g, p, pk, p.w_tr[i], W, p.k_tr[i]);
-    g.I = P; g.J = W; g.K = p.k_tr[i];
-    g.C = ws.f(p.o_h[i]); g.ldc = W;
-    g.bias = pk + p.b_tr[i]; g.act = act; g.w0 = (p.siren && i == 0) ? 30.f : 1.f;
-    if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_c[i]); else g.C2 = ws.f(p.o_c[i]); }
-    RC(launch_gemm(g, st));
-  }
-  const float* hl = ws.f(p.o_h[p.L - 1]);
-  {  // sigma pre-activation (rs_semantic.py:337) -> NARROW-wide buffer, column 0
-    GemmArgs g;
-    g.A = hl; g.lda = W; g.B = pk + p.w_fs + (size_t)W * W; g.ldb = W; g.I = P; g.J = NARROW; g.K = W;
-    g.C = ws.f(p.o_sigo); g.ldc = NARROW; g.bias = pk + p.b_fs + W; g.narrow_j = true;
-    RC(launch_gemm(g, st));
-  }
-  {  // feats (rs_semantic.py:338), written into the first W columns of the [feats | sun | t | t_s] buffer
-    GemmArgs g;
-    g.A = hl; g.lda = W; weights(g, p, pk, p.w_fs, W + NARROW, W); g.I = P; g.J = W; g.K = W;
-    g.C = ws.f(p.o_fa); g.ldc = p.FA; g.bias = pk + p.b_fs;
-   
-    RC(launch_gemm(g, st));
-  }
-  {  // first layer of every head in one GEMM (sc pass: sun-visibility block only)
-    GemmArgs g;
-    g.A = ws.f(p.o_fa); g.lda = p.FA; g.I = P; g.K = p.FA;
-    const size_t r0 = p.sc ? (size_t)p.sun_col : 0;
-    weights(g, p, pk, p.w_h1, p.N1, p.FA, (int)r0); g.J = p.h1w;
-    g.C = ws.f(p.o_h1); g.ldc = p.h1w; g.bias = pk + p.b_h1 + r0; g.act = act; g.w0 = 1.f;
-   
-    if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_c1); else g.C2 = ws.f(p.o_c1); }
-    RC(launch_gemm(g, st));
-  }
-  const int sun_col = p.sc ? 0 : p.sun_col;
-  {  // sun visibility layers 2,3 (rs_semantic.py:217-227)
-    GemmArgs g;
-    g.A = ws.f(p.o_h1) + sun_col; g.lda = p.h1w; weights(g, p, pk, p.w_s2, H, H); g.I = P; g.J = H; g.K = H;
-    g.C = ws.f(p.o_s2); g.ldc = H; g.bias = pk + p.b_s2; g.act = act;
-   
-    if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_cs2); else g.C2 = ws.f(p.o_cs2); }
-    RC(launch_gemm(g, st));
-    g.A = ws.f(p.o_s2); g.lda = H; weights(g, p, pk, p.w_s3, H, H); g.bias = pk + p.b_s3; g.C = ws.f(p.o_s3);
-   
-    if (p.train && p.siren) { if (p.sign_deriv) g.C2s = ws.u(p.o_cs3); else g.C2 = ws.f(p.o_cs3); }
-    RC(launch_gemm(g, st));
-  }
-  {  // sun visibility output pre-activation
-    GemmArgs g;
-    g.A = ws.f(p.o_s3); g.lda = H; g.B = pk + p.w_s4; g.ldb = H; g.I = P; g.J = NARROW; g.K = H;
-    g.C = ws.f(p.o_suno); g.ldc = NARROW; g.bias = pk + p.b_s4; g.narrow_j = true;
-    RC(launch_gemm(g, st));
-  }
-  if (!p.sc) {  // last layer of rgb / beta / beta_s / semantic heads: block-diagonal [NARROW][KF]
-    GemmArgs g;
-    g.A = ws.f(p.o_h1); g.lda = p.h1w; g.B = pk + p.w_fin; g.ldb = p.KF; g.I = P; g.J = NARROW; g.K = p.KF;
-    g.C = ws.f(p.o_fino); g.ldc = NARROW; g.bias = pk + p.b_fin; g.narrow_j = true;
-    RC(launch_gemm(g, st));
-  }
-  // 4. composite
-  CompArgs c;
-  c.N = p.N; c.S = p.S; c.H = H; c.C = p.C; c.sc = p.sc; c.sem_sigmoid = p.sem_sigmoid; c.has_sbeta = p.blk_sbeta >= 0;
-  c.z = z; c.sigo = ws.f(p.o_sigo); c.fino = ws.f(p.o_fino); c.suno = ws.f(p.o_suno);
-  c.sun_d = in->sun_d; c.sun_stride = in->sun_stride; c.sky = pk + p.sky;
-  c.o_rgb = out->rgb; c.o_depth = out->depth; c.o_weights = out->weights; c.o_transparency = out->transparency;
-  c.o_albedo = out->albedo; c.o_sun = out->sun; c.o_sky = out->sky; c.o_beta = out->beta; c.o_sigmas = out->sigmas;
-  c.o_beta_s = out->beta_semantic; c.o_logits = out->semantic_logits; c.o_label = (long long*)out->semantic_label;
-  if (p.train) { c.save_T = ws.f(p.o_T); c.save_rgbraw = ws.f(p.o_rgbraw); }
-  RC(launch_composite_fwd(c, st));
-  return SNERF_OK;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// backward
-// ---------------------------------------------------------------------------------------------------
-// dW = dZ^T X over all points, split-K into slabs, then one deterministic reduction into g (+=).
-struct DwMat {  // one parameter matrix [rows][ldw] being accumulated in the slab area
-  DwSplit sp; size_t stride; int ldw;
-};
-static DwMat dw_begin(const Plan& p, int rows, int ldw, int cols, bool narrow_rows) {
-  DwMat m;
-  m.sp = dw_choose(p.P, rows, cols, narrow_rows);
-  m.stride = round_up_sz((size_t)rows * ldw, 64);
-  m.ldw = ldw;
-  return m;
-}
-static int dw_gemm(const Plan& p, WS ws, const DwMat& m, const float* dz, int lddz, int I, bool narrow_i, const float* X,
-                   int ldx, int J, size_t slab_off, hipStream_t st) {
-  GemmArgs g;
-  g.A = dz; g.lda = lddz; g.a_ic = true; g.B = X; g.ldb = ldx; g.b_ic = true;
-  g.I = I; g.J = J; g.K = p.P;
-  g.C = ws.f(p.o_slab) + slab_off; g.ldc = m.ldw;
-  g.k_split = m.sp.k_split; g.n_split = m.sp.ns; g.slab_stride = m.stride; g.narrow_i = narrow_i; g.x6 = p.x6; g.planes = p.planes;
-  return launch_gemm(g, st);
-}
-static int dw_reduce(const Plan& p, WS ws, const DwMat& m, size_t count, float* gout, hipStream_t st) {
-  return reduce_partials(ws.f(p.o_slab), m.sp.ns, m.stride, (int)count, ws.f(p.o_slab2), gout, st);
-}
-static int bias_from_colsum(const Plan& p, WS ws, int width, float* gout, hipStream_t st) {
-  return reduce_partials(ws.f(p.o_colsum), p.nrb, (size_t)p.maxw, width, ws.f(p.o_colsum2), gout, st);
-}
-// bias gradient of a NARROW-wide pre-activation buffer
-static int bias_from_narrow(const Plan& p, WS ws, const float* dnar, float* gout, hipStream_t st) {
-  const int nb = colsum32_blocks(p.P);
-  RC(launch_colsum32(dnar, p.P, ws.f(p.o_colsum), st));
-  return reduce_partials(ws.f(p.o_colsum), nb, NARROW, NARROW, ws.f(p.o_colsum2), gout, st);
-}
-
-static int backward_impl(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutGrads* go, float* gp,
-                         float* d_t, float* d_t_s, WS ws, hipStream_t st) {
-  const int P = p.P, W = p.W, H = p.H;
-  // activation derivative applied in a dX epilogue.  siren: w0 * sign(cos) * sqrt(1 - h^2) from the stored activation
-  // h = sin(w0 z) (buffer o_h, leading dimension ld, column col0) and the sign words the forward launch wrote (o_c);
-  // relu: mask by h > 0.
-  auto dact = [&](GemmArgs& g, size_t o_c, size_t o_h, int ld, int col0 = 0, float w0 = 1.f) {
-    g.aux = ws.f(o_h) + col0; g.ldaux = ld;
-    if (p.siren && p.sign_deriv) { g.aux_mode = AUX_SINREC; g.aux_sign = ws.u(o_c); g.sign_col0 = col0; g.w0 = w0; }
-    else if (p.siren) { g.aux = ws.f(o_c) + col0; g.aux_mode = AUX_MUL; }
-    else g.aux_mode = AUX_RELU_MASK;
-  };
-  float* dsig = ws.f(p.o_dsig); float* dfin = ws.f(p.o_dfin); float* dsun = ws.f(p.o_dsun);
-  // 0. composite backward -> gradients of the NARROW-wide pre-activations (+ sky MLP grads)
-  CompBwdArgs b;
-  CompArgs& c = b.f;
-  c.N = p.N; c.S = p.S; c.H = H; c.C = p.C; c.sc = p.sc; c.sem_sigmoid = p.sem_sigmoid; c.has_sbeta = p.blk_sbeta >= 0;
-  c.z = ws.f(p.o_z); c.sigo = ws.f(p.o_sigo); c.fino = ws.f(p.o_fino); c.suno = ws.f(p.o_suno);
-  c.sun_d = in->sun_d; c.sun_stride = in->sun_stride; c.sky = pk + p.sky;
-  b.T = ws.f(p.o_T); b.rgbraw = ws.f(p.o_rgbraw);
-  b.g_rgb = go->rgb; b.g_depth = go->depth; b.g_weights = go->weights; b.g_transparency = go->transparency;
-  b.g_albedo = go->albedo; b.g_sun = go->sun; b.g_sky = go->sky; b.g_beta = go->beta; b.g_sigmas = go->sigmas;
-  b.g_beta_s = go->beta_semantic; b.g_logits = go->semantic_logits;
-  b.d_sigo = dsig; b.d_fino = dfin; b.d_suno = dsun; b.sky_slab = p.sc ? nullptr : ws.f(p.o_skyslab);
-  RC(launch_composite_bwd(b, st));
-  if (!p.sc)
-    RC(reduce_partials(ws.f(p.o_skyslab), p.comp_blocks * 4, (size_t)p.sky_floats, p.sky_floats, ws.f(p.o_colsum2),
-                       gp + p.sky, st));
-
-  float* dz1 = ws.f(p.o_dza);  // d(pre-activation) of the fused first head layer, [P][h1w]
-  const int sun_col = p.sc ? 0 : p.sun_col;
-  if (!p.sc) {
-    // 1. final head layers
-    const DwMat mf = dw_begin(p, NARROW, p.KF, p.KF, true);
-    RC(dw_gemm(p, ws, mf, dfin, NARROW, NARROW, true, ws.f(p.o_h1), p.h1w, p.KF, 0, st));
-    RC(dw_reduce(p, ws, mf, (size_t)NARROW * p.KF, gp + p.w_fin, st));
-    RC(bias_from_narrow(p, ws, dfin, gp + p.b_fin, st));
-    GemmArgs g;  // dz1[:, :KF] = (dfin . W_fin) * act'
-    g.A = dfin; g.lda = NARROW; weights(g, p, pk, p.t_fin, p.KF, NARROW); g.I = P; g.J = p.KF; g.K = NARROW;
-    g.C = dz1; g.ldc = p.h1w; dact(g, p.o_c1, p.o_h1, p.h1w);
-   
-    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
-    RC(launch_gemm(g, st));
-    RC(bias_from_colsum(p, ws, p.KF, gp + p.b_h1, st));
-  }
-  {  // 2. sun visibility chain: output layer, layer 3, layer 2
-    const DwMat m4 = dw_begin(p, NARROW, H, H, true);
-    const DwMat mh = dw_begin(p, H, H, H, false);
-    RC(dw_gemm(p, ws, m4, dsun, NARROW, NARROW, true, ws.f(p.o_s3), H, H, 0, st));
-    RC(dw_reduce(p, ws, m4, (size_t)NARROW * H, gp + p.w_s4, st));
-    RC(bias_from_narrow(p, ws, dsun, gp + p.b_s4, st));
-    GemmArgs g;
-    g.A = dsun; g.lda = NARROW; weights(g, p, pk, p.t_s4, H, NARROW); g.I = P; g.J = H; g.K = NARROW;
-    g.C = ws.f(p.o_dsa); g.ldc = H; dact(g, p.o_cs3, p.o_s3, H);
-   
-    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
-    RC(launch_gemm(g, st));  // dz_s3
-    RC(bias_from_colsum(p, ws, H, gp + p.b_s3, st));
-    RC(dw_gemm(p, ws, mh, ws.f(p.o_dsa), H, H, false, ws.f(p.o_s2), H, H, 0, st));
-    RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s3, st));
-    g.A = ws.f(p.o_dsa); g.lda = H; weights(g, p, pk, p.t_s3, H, H); g.K = H;
-    g.C = ws.f(p.o_dsb); dact(g, p.o_cs2, p.o_s2, H);
-   
-    RC(launch_gemm(g, st));  // dz_s2
-    RC(bias_from_colsum(p, ws, H, gp + p.b_s2, st));
-    RC(dw_gemm(p, ws, mh, ws.f(p.o_dsb), H, H, false, ws.f(p.o_h1) + sun_col, p.h1w, H, 0, st));
-    RC(dw_reduce(p, ws, mh, (size_t)H * H, gp + p.w_s2, st));
-    g.A = ws.f(p.o_dsb); weights(g, p, pk, p.t_s2, H, H);
-    g.C = dz1 + sun_col; g.ldc = p.h1w; dact(g, p.o_c1, p.o_h1, p.h1w, sun_col);
-   
-    RC(launch_gemm(g, st));  // dz1[:, sun block]
-    RC(bias_from_colsum(p, ws, H, gp + p.b_h1 + (size_t)p.sun_col, st));
-  }
-  float* dfa = ws.f(p.o_dzb);  // [P][FA]
-  {  // 3. fused first head layer: dW, then d[feats | extras]
-    const size_t r0 = p.sc ? (size_t)p.sun_col : 0;
-    const DwMat m1 = dw_begin(p, p.h1w, p.FA, p.FA, false);
-    RC(dw_gemm(p, ws, m1, dz1, p.h1w, p.h1w, false, ws.f(p.o_fa), p.FA, p.FA, 0, st));
-    RC(dw_reduce(p, ws, m1, (size_t)p.h1w * p.FA, gp + p.w_h1 + r0 * p.FA, st));
-    GemmArgs g;
-    g.A = dz1; g.lda = p.h1w; weights(g, p, pk, p.t_h1, p.FA, p.N1, 0, (int)r0);
-    g.I = P; g.J = p.FA; g.K = p.h1w; g.C = dfa; g.ldc = p.FA;
-   
-    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;  // columns [0,W) = bias grad of feats_from_xyz
-    RC(launch_gemm(g, st));
-    RC(bias_from_colsum(p, ws, W, gp + p.b_fs, st));
-    if (d_t) RC(launch_ray_sum(dfa, p.FA, p.Wf + p.x_t, p.N, p.S, p.tau, d_t, st));
-    if (d_t_s && p.x_ts >= 0) RC(launch_ray_sum(dfa, p.FA, p.Wf + p.x_ts, p.N, p.S, p.tau, d_t_s, st));
-  }
-  float* dz = ws.f(p.o_dza);  // dz1 is dead from here on
-  {  // 4. feats + sigma: dW for the [W + NARROW][W] matrix, then dz of the last trunk layer
-    const float* hl = ws.f(p.o_h[p.L - 1]);
-    const DwMat ms = dw_begin(p, W + NARROW, W, W, false);
-    RC(dw_gemm(p, ws, ms, dfa, p.FA, W, false, hl, W, W, 0, st));
-    RC(dw_gemm(p, ws, ms, dsig, NARROW, NARROW, true, hl, W, W, (size_t)W * W, st));
-    RC(dw_reduce(p, ws, ms, (size_t)(W + NARROW) * W, gp + p.w_fs, st));
-    RC(bias_from_narrow(p, ws, dsig, gp + p.b_fs + W, st));
-    GemmArgs g;
-    g.A = dfa; g.lda = p.FA; g.Ka = W; g.A2 = dsig; g.lda2 = NARROW;
-    weights(g, p, pk, p.t_fs, W, W + NARROW); g.I = P; g.J = W; g.K = W + NARROW;
-    g.C = dz; g.ldc = W; dact(g, p.o_c[p.L - 1], p.o_h[p.L - 1], W, 0, (p.L == 1) ? 30.f : 1.f);
-   
-    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
-    RC(launch_gemm(g, st));
-    RC(bias_from_colsum(p, ws, W, gp + p.b_tr[p.L - 1], st));
-  }
-  // 5. trunk, last layer to first
-  float* dz_cur = dz;
-  float* dz_nxt = ws.f(p.o_dzb);
-  for (int i = p.L - 1; i >= 0; --i) {
-    const bool skip = (p.skip_mask >> i) & 1u;
-    const int hoff = (i > 0 && skip) ? p.Ep : 0;  // column of the h part inside W_i
-    const DwMat mt = dw_begin(p, W, p.k_tr[i], i == 0 ? p.Ep : W, false);
-    if (i == 0 || skip) RC(dw_gemm(p, ws, mt, dz_cur, W, W, false, ws.f(p.o_pe), p.Ep, p.Ep, 0, st));
-    if (i > 0) RC(dw_gemm(p, ws, mt, dz_cur, W, W, false, ws.f(p.o_h[i - 1]), W, W, hoff, st));
-    RC(dw_reduce(p, ws, mt, (size_t)W * p.k_tr[i], gp + p.w_tr[i], st));
-    if (i == 0) break;
-    GemmArgs g;
-    g.A = dz_cur; g.lda = W; weights(g, p, pk, p.t_tr[i], W, W);
-    g.I = P; g.J = W; g.K = W; g.C = dz_nxt; g.ldc = W;
-    dact(g, p.o_c[i - 1], p.o_h[i - 1], W, 0, (i - 1 == 0) ? 30.f : 1.f);
-   
-    g.colsum = ws.f(p.o_colsum); g.ldcs = p.maxw;
-    RC(launch_gemm(g, st));
-    RC(bias_from_colsum(p, ws, W, gp + p.b_tr[i - 1], st));
-    float* t = dz_cur; dz_cur = dz_nxt; dz_nxt = t;
-  }
-  return SNERF_OK;
-}
 
 static int check_inputs(const Plan& p, const SnerfInputs* in) {
   if (!in) { set_error("null inputs"); return SNERF_ERR_NULL; }
@@ -683,37 +313,13 @@ int snerf_pack_params(const SnerfDesc* desc, const SnerfParams* params, float* p
   hipStream_t st = (hipStream_t)stream;
   RC(launch_zero_bytes(packed, p.n_fp32 * sizeof(float), st));
   for (int i = 0; i < tb.nt; ++i) RC(launch_copy_table(tb.tabs[i], packed, 0, st));
-  if (p.fmt == 1) {
-    // default arithmetic: every weight operand (matrix or its transpose) as a fragment-ordered fp16-plane pack with one
-    // exponent per matrix -- two launches over a job table (|max| pass, pack pass)
-    bsp::WPackTable wt;
-    build_wjobs(p, wt);
-    char* planes = reinterpret_cast<char*>(packed + p.n_fp32);
-    int* exps = reinterpret_cast<int*>(planes + p.wp_bytes);
-    return bsp::launch_wpack(wt, packed, planes, exps, reinterpret_cast<unsigned*>(exps + Plan::WJ_MAX), st);
-  }
-  // K-contiguous transposes consumed by the dX GEMMs
-  for (int i = 1; i < p.L; ++i) {
-    const int hoff = ((p.skip_mask >> i) & 1u) ? p.Ep : 0;
-    RC(launch_transpose(packed + p.w_tr[i] + hoff, p.k_tr[i], p.W, p.W, packed + p.t_tr[i], p.W, st));
-  }
-  RC(launch_transpose(packed + p.w_fs, p.W, p.W + NARROW, p.W, packed + p.t_fs, p.W + NARROW, st));
-  RC(launch_transpose(packed + p.w_h1, p.FA, p.N1, p.FA, packed + p.t_h1, p.N1, st));
-  RC(launch_transpose(packed + p.w_s2, p.H, p.H, p.H, packed + p.t_s2, p.H, st));
-  RC(launch_transpose(packed + p.w_s3, p.H, p.H, p.H, packed + p.t_s3, p.H, st));
-  RC(launch_transpose(packed + p.w_s4, p.H, NARROW, p.H, packed + p.t_s4, NARROW, st));
-  RC(launch_transpose(packed + p.w_fin, p.KF, NARROW, p.KF, packed + p.t_fin, NARROW, st));
-  // pre-split, k-tile-major bf16 planes of every matrix that is the weight operand of a 128x128 GEMM
-  unsigned short* pl0 = reinterpret_cast<unsigned short*>(packed + p.n_fp32);
-  auto planes = [&](size_t mat, int rows, int ld) { return launch_split_planes(packed + mat, rows, ld, pl0 + mat, p.n_fp32, st); };
-  for (int i = 0; i < p.L; ++i) RC(planes(p.w_tr[i], p.W, p.k_tr[i]));
-  for (int i = 1; i < p.L; ++i) RC(planes(p.t_tr[i], p.W, p.W));
-  RC(planes(p.w_fs, p.W + NARROW, p.W)); RC(planes(p.t_fs, p.W, p.W + NARROW));
-  RC(planes(p.w_h1, p.N1, p.FA)); RC(planes(p.t_h1, p.FA, p.N1));
-  RC(planes(p.w_s2, p.H, p.H)); RC(planes(p.t_s2, p.H, p.H));
-  RC(planes(p.w_s3, p.H, p.H)); RC(planes(p.t_s3, p.H, p.H));
-  RC(planes(p.t_s4, p.H, NARROW)); RC(planes(p.t_fin, p.KF, NARROW));
-  return SNERF_OK;
+  // every weight operand (matrix or its transpose) as a fragment-ordered fp16-plane pack with one exponent per matrix -- two
+  // launches over a job table (|max| pass, pack pass)
+  bsp::WPackTable wt;
+  build_wjobs(p, wt);
+  char* planes = reinterpret_cast<char*>(packed + p.n_fp32);
+  int* exps = reinterpret_cast<int*>(planes + p.wp_bytes);
+  return bsp::launch_wpack(wt, packed, planes, exps, reinterpret_cast<unsigned*>(exps + Plan::WJ_MAX), p.pl, st);
 }
 
 int snerf_unpack_grads(const SnerfDesc* desc, const float* packed_grads, const SnerfParams* grads, int accumulate,
@@ -737,9 +343,7 @@ int snerf_forward(const SnerfDesc* desc, const float* packed_params, const Snerf
   if (workspace_bytes < p.ws_bytes) { set_error("snerf_forward: workspace too small (%zu < %zu)", workspace_bytes, p.ws_bytes); return SNERF_ERR_WORKSPACE; }
   if (((uintptr_t)workspace & 255) || ((uintptr_t)packed_params & 255)) { set_error("workspace and packed params must be 256-byte aligned"); return SNERF_ERR_WORKSPACE; }
   RC(check_inputs(p, in));
-  if (p.fmt == 1) return forward_bsp(p, packed_params, in, out, workspace, (hipStream_t)stream);
-  WS ws{(char*)workspace};
-  return forward_impl(p, packed_params, in, out, ws, (hipStream_t)stream);
+  return forward_bsp(p, packed_params, in, out, workspace, (hipStream_t)stream);
 }
 
 int snerf_backward(const SnerfDesc* desc, const float* packed_params, const SnerfInputs* in, const SnerfOutGrads* gout,
@@ -751,10 +355,7 @@ int snerf_backward(const SnerfDesc* desc, const float* packed_params, const Sner
   if (workspace_bytes < p.ws_bytes) { set_error("snerf_backward: workspace too small (%zu < %zu)", workspace_bytes, p.ws_bytes); return SNERF_ERR_WORKSPACE; }
   if (((uintptr_t)workspace & 255) || ((uintptr_t)packed_params & 255) || ((uintptr_t)packed_grads & 255)) { set_error("workspace and packed buffers must be 256-byte aligned"); return SNERF_ERR_WORKSPACE; }
   RC(check_inputs(p, in));
-  if (p.fmt == 1) return backward_bsp(p, packed_params, in, gout, packed_grads, d_t, d_t_s, workspace, (hipStream_t)stream);
-  WS ws{(char*)workspace};
-  if ((desc->flags & SNERF_FLAG_BWD_BF16X3) && p.x6 && p.fmt == 0 && p.planes == 3) p.planes = 2;  // same Plan, fewer products in backward
-  return backward_impl(p, packed_params, in, gout, packed_grads, d_t, d_t_s, ws, (hipStream_t)stream);
+  return backward_bsp(p, packed_params, in, gout, packed_grads, d_t, d_t_s, workspace, (hipStream_t)stream);
 }
 
 int snerf_sample_z(const float* rays, const float* z_steps, const float* u, float* z, int n_rays, int n_samples, void* stream) {
@@ -775,29 +376,18 @@ int snerf_embedding_backward(const long long* idx, const float* d_rows, int n, i
 int snerf_profile_begin(void) { return profile_begin(); }
 int snerf_profile_end(SnerfProfile* out) { return profile_end(out); }
 
-int snerf_test_gemm(const float* A, int lda, int a_ic, const float* B, int ldb, int b_ic, float* C, int ldc, int I,
-                    int J, int K, int narrow, void* stream) {
-  GemmArgs g;
-  g.A = A; g.lda = lda; g.a_ic = a_ic != 0; g.B = B; g.ldb = ldb; g.b_ic = b_ic != 0;
-  g.C = C; g.ldc = ldc; g.I = I; g.J = J; g.K = K;
-  g.narrow_j = (narrow & 3) == 1; g.narrow_i = (narrow & 3) == 2; g.x6 = (narrow & 4) != 0;
-  g.planes = (narrow & 8) ? 1 : ((narrow & 16) ? 2 : 3);
-  g.tile = (narrow & 32) ? 256 : ((narrow & 64) ? 128 : 0);
-  return launch_gemm(g, (hipStream_t)stream);
-}
-
 // ---- test hooks of the block-scaled plane kernels (tests/test_gpu_bsp.py): fp32 in / fp32 out around ONE launch of the
 // kernel under test; the conversions run through the library's own to_planes / from_planes / weight pack.  Synchronous,
 // allocating -- never on the product path.
 
-int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int col0, float* dst, int* exps_out, void* stream) {
+int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int col0, float* dst, int* exps_out, int planes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   DevBuf pl, E;
   const size_t rp = round_up_sz(rows, 128);
-  TALLOC(pl, bsp::plane_bytes(rp, ld)); TALLOC(E, bsp::etab_ints(rp, ld) * 4);
+  TALLOC(pl, bsp::plane_bytes(rp, ld, planes)); TALLOC(E, bsp::etab_ints(rp, ld) * 4);
   SNERF_HIP_CHECK(hipMemsetAsync(E.p, 0, bsp::etab_ints(rp, ld) * 4, st));
-  RC(bsp::launch_to_planes(src, cols, rows, cols, pl.as<char>(), E.as<int>(), ld, col0, st));
-  RC(bsp::launch_from_planes(pl.as<char>(), E.as<int>(), ld, col0, rows, cols, dst, cols, st));
+  RC(bsp::launch_to_planes(src, cols, rows, cols, pl.as<char>(), E.as<int>(), ld, col0, planes, st));
+  RC(bsp::launch_from_planes(pl.as<char>(), E.as<int>(), ld, col0, rows, cols, dst, cols, planes, st));
   if (exps_out) SNERF_HIP_CHECK(hipMemcpyAsync(exps_out, E.p, bsp::etab_ints(rp, ld) * 4, hipMemcpyDeviceToDevice, st));
   SNERF_HIP_CHECK(hipStreamSynchronize(st));
   return SNERF_OK;
@@ -811,25 +401,32 @@ int snerf_test_set_kc_grid(int n) { bsp::kc_set_grid_override(n); return SNERF_O
 // tensors and the output at column c_col0 (exercises the column-offset / exponent-block arithmetic).
 int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, const float* bias, int I, int J, int K, int a_col0,
                       int c_col0, int act, float w0, int aux_mode, const float* Hact, const unsigned* Hsign, float* C,
-                      unsigned* Csign, float* colsum, int narrow, void* stream) {
+                      unsigned* Csign, float* colsum, int narrow, int planes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (K % 16 || Ka % 16 || Ka <= 0 || Ka > K) { set_error("test_bsp_kc: K, Ka % 16"); return SNERF_ERR_BAD_DESC; }
+  if (planes != 1 && planes != 2) { set_error("test_bsp_kc: planes"); return SNERF_ERR_BAD_DESC; }
+  const int pl = planes;
   const size_t rp = round_up_sz(I, 128);
   const int lda = a_col0 + Ka, lda2 = K > Ka ? K - Ka : 16, ldc = c_col0 + round_up(J, 16);
   DevBuf pa, ea, pa2, ea2, wp, we, wm, pc, ec, ph, eh;
-  TALLOC(pa, bsp::plane_bytes(rp, lda)); TALLOC(ea, bsp::etab_ints(rp, lda) * 4);
-  TALLOC(pa2, bsp::plane_bytes(rp, lda2)); TALLOC(ea2, bsp::etab_ints(rp, lda2) * 4);
-  RC(bsp::launch_to_planes(A, Ka, I, Ka, pa.as<char>(), ea.as<int>(), lda, a_col0 & ~127, st));
+  // (+ 64 pad columns: a one-plane launch whose K is an odd multiple of 16 reads -- against zero weights -- up to 16 columns
+  //  beyond K; in the passes those are the next row's columns, here they must not be uninitialised memory)
+  TALLOC(pa, bsp::plane_bytes(rp + 1, lda, pl)); TALLOC(ea, bsp::etab_ints(rp, lda) * 4);
+  TALLOC(pa2, bsp::plane_bytes(rp + 1, lda2, pl)); TALLOC(ea2, bsp::etab_ints(rp, lda2) * 4);
+  SNERF_HIP_CHECK(hipMemsetAsync(pa.p, 0, bsp::plane_bytes(rp + 1, lda, pl), st));
+  SNERF_HIP_CHECK(hipMemsetAsync(pa2.p, 0, bsp::plane_bytes(rp + 1, lda2, pl), st));
+  RC(bsp::launch_to_planes(A, Ka, I, Ka, pa.as<char>(), ea.as<int>(), lda, a_col0 & ~127, pl, st));
   if (a_col0 & 127) { set_error("test_bsp_kc: a_col0 % 128"); return SNERF_ERR_BAD_DESC; }
-  if (K > Ka) RC(bsp::launch_to_planes(A2, K - Ka, I, K - Ka, pa2.as<char>(), ea2.as<int>(), lda2, 0, st));
+  if (K > Ka) RC(bsp::launch_to_planes(A2, K - Ka, I, K - Ka, pa2.as<char>(), ea2.as<int>(), lda2, 0, pl, st));
   bsp::WPackTable tb; tb.n = 1;
   tb.j[0] = bsp::WPackJob{0ull, K, J, K, 0, 0ull, 0, J, K};
-  TALLOC(wp, bsp::wp16_bytes(J, K)); TALLOC(we, bsp::WPACK_MAX * 4); TALLOC(wm, bsp::WPACK_MAX * 4);
-  RC(bsp::launch_wpack(tb, W, wp.as<char>(), we.as<int>(), wm.as<unsigned>(), st));
+  TALLOC(wp, bsp::wp16_bytes(J, K, pl)); TALLOC(we, bsp::WPACK_MAX * 4); TALLOC(wm, bsp::WPACK_MAX * 4);
+  RC(bsp::launch_wpack(tb, W, wp.as<char>(), we.as<int>(), wm.as<unsigned>(), pl, st));
   bsp::KcArgs g;
+  g.pl = pl;
   g.A = pa.as<char>(); g.EA = ea.as<int>(); g.lda = lda; g.a_col0 = a_col0; g.Ka = Ka;
   if (K > Ka) { g.A2 = pa2.as<char>(); g.EA2 = ea2.as<int>(); g.lda2 = lda2; g.a2_col0 = 0; }
-  g.W = wp.as<char>(); g.EW = we.as<int>(); g.w_rb32 = (J + 31) / 32; g.w_bytes = (unsigned)bsp::wp16_bytes(J, K);
+  g.W = wp.as<char>(); g.EW = we.as<int>(); g.w_rb32 = (J + 31) / 32; g.w_bytes = (unsigned)bsp::wp16_bytes(J, K, pl);
   g.I = I; g.J = J; g.K = K; g.bias = bias; g.act = act; g.w0 = w0;
   if (narrow) {
     g.Cf = C;
@@ -837,11 +434,11 @@ int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, c
     SNERF_HIP_CHECK(hipStreamSynchronize(st));
     return SNERF_OK;
   }
-  TALLOC(pc, bsp::plane_bytes(rp, ldc)); TALLOC(ec, bsp::etab_ints(rp, ldc) * 4);
+  TALLOC(pc, bsp::plane_bytes(rp, ldc, pl)); TALLOC(ec, bsp::etab_ints(rp, ldc) * 4);
   g.C = pc.as<char>(); g.EC = ec.as<int>(); g.ldc = ldc; g.c_col0 = c_col0; g.Csign = Csign;
   if (aux_mode != AUX_NONE) {
-    TALLOC(ph, bsp::plane_bytes(rp, ldc)); TALLOC(eh, bsp::etab_ints(rp, ldc) * 4);
-    RC(bsp::launch_to_planes(Hact, J, I, J, ph.as<char>(), eh.as<int>(), ldc, c_col0, st));
+    TALLOC(ph, bsp::plane_bytes(rp, ldc, pl)); TALLOC(eh, bsp::etab_ints(rp, ldc) * 4);
+    RC(bsp::launch_to_planes(Hact, J, I, J, ph.as<char>(), eh.as<int>(), ldc, c_col0, pl, st));
     g.aux_mode = aux_mode; g.H = ph.as<char>(); g.EH = eh.as<int>(); g.ldh = ldc; g.h_col0 = c_col0; g.Hsign = Hsign;
   }
   g.colsum = colsum; g.ldcs = J;
@@ -849,29 +446,31 @@ int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, c
   SNERF_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, st));
   g.tile_ctr = ctr.as<int>();
   RC(bsp::launch_kc(g, st));
-  RC(bsp::launch_from_planes(pc.as<char>(), ec.as<int>(), ldc, c_col0, I, J, C, J, st));
+  RC(bsp::launch_from_planes(pc.as<char>(), ec.as<int>(), ldc, c_col0, I, J, C, J, pl, st));
   SNERF_HIP_CHECK(hipStreamSynchronize(st));
   return SNERF_OK;
 }
 
 // C[I][J] = sum_p A[p][a_col0 + i] B[p][b_col0 + j] through split-K slabs + the library's deterministic slab reduction
 int snerf_test_bsp_dw(const float* A, int lda_src, const float* B, int ldb_src, int P, int I, int J, int a_col0, int b_col0,
-                      int k_split, int narrow_i, float* C, void* stream) {
+                      int k_split, int narrow_i, float* C, int planes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
+  if (planes != 1 && planes != 2) { set_error("test_bsp_dw: planes"); return SNERF_ERR_BAD_DESC; }
+  const int pl = planes;
   const size_t rp = round_up_sz(P, 128);
   const int lda = round_up(lda_src, 16), ldb = round_up(ldb_src, 16);
   DevBuf pa, ea, pb, eb, slab, tmp;
-  TALLOC(pa, bsp::plane_bytes(rp, lda)); TALLOC(ea, bsp::etab_ints(rp, lda) * 4);
-  TALLOC(pb, bsp::plane_bytes(rp, ldb)); TALLOC(eb, bsp::etab_ints(rp, ldb) * 4);
-  RC(bsp::launch_to_planes(A, lda_src, P, lda_src, pa.as<char>(), ea.as<int>(), lda, 0, st));
-  RC(bsp::launch_to_planes(B, ldb_src, P, ldb_src, pb.as<char>(), eb.as<int>(), ldb, 0, st));
+  TALLOC(pa, bsp::plane_bytes(rp, lda, pl)); TALLOC(ea, bsp::etab_ints(rp, lda) * 4);
+  TALLOC(pb, bsp::plane_bytes(rp, ldb, pl)); TALLOC(eb, bsp::etab_ints(rp, ldb) * 4);
+  RC(bsp::launch_to_planes(A, lda_src, P, lda_src, pa.as<char>(), ea.as<int>(), lda, 0, pl, st));
+  RC(bsp::launch_to_planes(B, ldb_src, P, ldb_src, pb.as<char>(), eb.as<int>(), ldb, 0, pl, st));
   const int ns = (P + k_split - 1) / k_split;
   const size_t stride = round_up_sz((size_t)I * J, 64);
   TALLOC(slab, stride * ns * 4); TALLOC(tmp, 64 * stride * 4);
   bsp::DwArgs g;
   g.A = pa.as<char>(); g.EA = ea.as<int>(); g.lda = lda; g.a_col0 = a_col0;
   g.B = pb.as<char>(); g.EB = eb.as<int>(); g.ldb = ldb; g.b_col0 = b_col0;
-  g.I = I; g.J = J; g.P = P; g.C = slab.as<float>(); g.ldc = J; g.k_split = k_split; g.n_split = ns; g.slab_stride = stride;
+  g.I = I; g.J = J; g.P = P; g.C = slab.as<float>(); g.ldc = J; g.k_split = k_split; g.n_split = ns; g.slab_stride = stride; g.pl = pl;
   RC(bsp::launch_dw(g, narrow_i != 0, st));
   SNERF_HIP_CHECK(hipMemsetAsync(C, 0, (size_t)I * J * 4, st));
   RC(reduce_partials(slab.as<float>(), ns, stride, I * J, tmp.as<float>(), C, st));

@@ -12,8 +12,7 @@ struct EncodeArgs {
   const float* t = nullptr; const float* t_s = nullptr;
   int dir_is_sun = 0;            // solar-correction pass: x = o + sun_d * z
   int N = 0, S = 0, F = 0, Ep = 0;
-  float* pe = nullptr;           // [P][Ep]
-  float* fa = nullptr; int FA = 0, W = 0, Xp = 0, x_sun = 0, x_t = 3, x_ts = -1, tau = 0;
+  int FA = 0, W = 0, Xp = 0, x_sun = 0, x_t = 3, x_ts = -1, tau = 0;
 };
 
 struct CopyEntry {
@@ -24,10 +23,7 @@ struct CopyTable { CopyEntry e[COPY_TABLE_MAX]; int n; };
 
 int launch_zero_bytes(void* p, size_t bytes, hipStream_t st);   // bytes % 4 == 0; a kernel, not a memset node (see aux_kernels.hip)
 int launch_sample_z(const float* rays, const float* zsteps, const float* u, float* z, int N, int S, hipStream_t st);
-int launch_encode(const EncodeArgs& a, hipStream_t st);
 int launch_copy_table(const CopyTable& tb, float* packed, int mode, hipStream_t st);
-int launch_transpose(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t st);
-int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes, size_t plane_stride, hipStream_t st);
 int launch_reduce_rows(const float* in, int n_in, size_t in_stride, int width, float* out, size_t out_stride,
                        int group, int accumulate, hipStream_t st);
 int reduce_partials(const float* in, int n_in, size_t in_stride, int width, float* tmp, float* out, hipStream_t st);
@@ -40,10 +36,7 @@ struct RedChunk { RedJob j[RED_CHUNK]; int n = 0; };                      // wha
 int red_add_elem(RedTable& tb, const float* in, int n_in, size_t stride, size_t width, float* out);   // few slabs, many elements
 int red_add_col(RedTable& tb, const float* in, int n_in, size_t stride, int width, float* out);       // many partial rows, <= ~1024 columns
 int launch_reductions(const RedTable& elem, const RedTable& col, hipStream_t st);
-int colsum32_blocks(int rows);   // partial rows launch_colsum32 writes
-int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st);
 int launch_embedding_rows(const float* table, int n_embed, int tau, const long long* idx, int n, float* rows, hipStream_t st);
 int launch_embedding_backward(const long long* idx, const float* d_rows, int n, int tau, int n_embed, float* grad, hipStream_t st);
-int launch_ray_sum(const float* dfa, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st);
 
 }  // namespace snerf

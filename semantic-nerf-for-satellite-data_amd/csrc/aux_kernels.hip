@@ -49,65 +49,6 @@ int launch_sample_z(const float* rays, const float* zsteps, const float* u, floa
   return 0;
 }
 
-// ---- sample position + positional encoding + per-sample extras ----------------------------------------
-// x = o + d*z (framework/components/rendering.py:113-115; d = sun_d for the solar-correction pass,
-// semantic/components/rendering.py:61-63); gamma(x) = [sin(2^k x), cos(2^k x)]_k, 3-wide blocks, no raw x
-// (baseline/models/commons.py:58-74); identity for the baseline SatNeRF.  One thread per (point, k):
-// the F threads of a point write one contiguous Ep-float row.  The k == 0 thread also writes the
-// [sun | t | t_s] columns behind the feats columns (never materialised by repeat_interleave as in
-// rs_semantic.py:42-61; written once per sample because the head GEMM reads them as K columns).
-__global__ void encode_kernel(EncodeArgs a) {
-  const int F = a.F > 0 ? a.F : 1;
-  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long point = g / F;
-  const int k = (int)(g - point * F);
-  if (point >= (long long)a.N * a.S) return;
-  const int n = (int)(point / a.S);
-  float x[3];
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    if (a.xyz != nullptr) {
-      x[c] = a.xyz[point * 3 + c];
-    } else {
-      const float o = a.rays[n * 8 + c];
-      const float d = a.dir_is_sun ? a.sun_d[(size_t)n * a.sun_stride + c] : a.rays[n * 8 + 3 + c];
-      x[c] = add_nofma(o, mul_nofma(d, a.z[point]));
-    }
-  }
-  float* pe = a.pe + point * a.Ep;
-  if (a.F > 0) {
-    const float f = (float)(1 << k);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float s, co;
-      sincos_acc(f * x[c], &s, &co);
-      pe[k * 6 + c] = s;
-      pe[k * 6 + 3 + c] = co;
-    }
-    if (k == 0)
-      for (int c = 6 * a.F; c < a.Ep; ++c) pe[c] = 0.f;  // pad columns are read by the GEMM (zero weights)
-  } else {
-    pe[0] = x[0]; pe[1] = x[1]; pe[2] = x[2];
-    for (int c = 3; c < a.Ep; ++c) pe[c] = 0.f;
-  }
-  if (k == 0 && a.fa != nullptr) {
-    float* e = a.fa + point * a.FA + a.W;
-    for (int c = 0; c < a.Xp; ++c) e[c] = 0.f;
-    for (int c = 0; c < 3; ++c) e[a.x_sun + c] = a.sun_d[(size_t)n * a.sun_stride + c];
-    if (a.t != nullptr)
-      for (int c = 0; c < a.tau; ++c) e[a.x_t + c] = a.t[(size_t)n * a.tau + c];
-    if (a.t_s != nullptr && a.x_ts >= 0)
-      for (int c = 0; c < a.tau; ++c) e[a.x_ts + c] = a.t_s[(size_t)n * a.tau + c];
-  }
-}
-
-int launch_encode(const EncodeArgs& a, hipStream_t st) {
-  const long long n = (long long)a.N * a.S * (a.F > 0 ? a.F : 1);
-  hipLaunchKernelGGL(encode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
-  SNERF_LAUNCH_CHECK();
-  return 0;
-}
-
 // ---- parameter pack / gradient unpack ---------------------------------------------------------------
 __global__ void copy_table_kernel(CopyTable tb, float* __restrict__ packed, int mode) {
   const CopyEntry e = tb.e[blockIdx.x];
@@ -125,54 +66,6 @@ __global__ void copy_table_kernel(CopyTable tb, float* __restrict__ packed, int 
 int launch_copy_table(const CopyTable& tb, float* packed, int mode, hipStream_t st) {
   if (tb.n <= 0) return 0;
   hipLaunchKernelGGL(copy_table_kernel, dim3(tb.n, 64), dim3(256), 0, st, tb, packed, mode);   // 64 workgroups per tensor: the 512 x 512 ones are 1 MB each
-  SNERF_LAUNCH_CHECK();
-  return 0;
-}
-
-// dst[c][r] = src[r][c] for a [rows][cols] block (32x32 tiles through LDS; both sides coalesced)
-__global__ void transpose_kernel(const float* __restrict__ src, int ld_src, int rows, int cols, float* __restrict__ dst,
-                                 int ld_dst) {
-  __shared__ float tile[32][33];
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
-  for (int j = ty; j < 32; j += 8)
-    if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = src[(size_t)(r0 + j) * ld_src + c0 + tx];
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8)
-    if (c0 + j < cols && r0 + tx < rows) dst[(size_t)(c0 + j) * ld_dst + r0 + tx] = tile[tx][j];
-}
-
-int launch_transpose(const float* src, int ld_src, int rows, int cols, float* dst, int ld_dst, hipStream_t st) {
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, src, ld_src, rows, cols,
-                     dst, ld_dst);
-  SNERF_LAUNCH_CHECK();
-  return 0;
-}
-
-// fp32 weight matrix [rows][ld] (ld % 16 == 0) -> three bf16 planes (hi | mid | lo, each the bf16 rounding of the
-// running residual: x = hi + mid + lo to 2^-26 relative), stored k-tile-major [ld/16][rows][16] with the LDS image's
-// swizzle baked in (the two 8-k halves of a row swap on rows with bit 3 set): a 128-row x 16-k tile is then 4 KB
-// of contiguous memory that the GEMM copies to LDS verbatim.  Plane p at planes + p*plane_stride.
-__global__ void split_planes_kernel(const float* __restrict__ x, int rows, int ld, unsigned short* __restrict__ planes,
-                                    size_t plane_stride) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)rows * ld) return;
-  const int r = (int)(i / ld), k = (int)(i - (size_t)r * ld);
-  const int kk = k & 15;
-  const size_t o = ((size_t)(k >> 4) * rows + r) * 16 + ((((kk >> 3) ^ (r >> 3)) & 1) << 3) + (kk & 7);
-  const float v = x[i];
-  const __bf16 h = (__bf16)v;
-  const float r1 = v - (float)h;
-  const __bf16 m = (__bf16)r1;
-  const __bf16 l = (__bf16)(r1 - (float)m);
-  planes[o] = __builtin_bit_cast(unsigned short, h);
-  planes[plane_stride + o] = __builtin_bit_cast(unsigned short, m);
-  planes[2 * plane_stride + o] = __builtin_bit_cast(unsigned short, l);
-}
-
-int launch_split_planes(const float* x, int rows, int ld, unsigned short* planes, size_t plane_stride, hipStream_t st) {
-  const size_t n = (size_t)rows * ld;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, rows, ld, planes, plane_stride);
   SNERF_LAUNCH_CHECK();
   return 0;
 }
@@ -405,54 +298,5 @@ int launch_reductions(const RedTable& elem, const RedTable& col, hipStream_t st)
 }
 
 // column sums of a [rows][32] buffer -> partial[blocks][32] (256 rows per block, float4 loads: 8 lanes per row)
-constexpr int CS32_ROWS = 256;
-__global__ __launch_bounds__(256) void colsum32_kernel(const float* __restrict__ in, int rows, float* __restrict__ partial) {
-  __shared__ float4 sm[32][8];
-  const int c4 = threadIdx.x & 7, rg = threadIdx.x >> 3;   // 32 row groups x 8 column quads
-  const int r0 = blockIdx.x * CS32_ROWS;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int i = 0; i < CS32_ROWS / 32; ++i) {
-    const int r = r0 + rg + 32 * i;
-    if (r < rows) {
-      const float4 v = *reinterpret_cast<const float4*>(in + (size_t)r * 32 + 4 * c4);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-  }
-  sm[rg][c4] = s;
-  __syncthreads();
-  if (threadIdx.x < 8) {   // fixed summation order over the 32 row groups
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < 32; ++i) { const float4 v = sm[i][threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-    *reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * 32 + 4 * threadIdx.x) = t;
-  }
-}
-
-int colsum32_blocks(int rows) { return (rows + CS32_ROWS - 1) / CS32_ROWS; }
-
-int launch_colsum32(const float* in, int rows, float* partial, hipStream_t st) {
-  hipLaunchKernelGGL(colsum32_kernel, dim3(colsum32_blocks(rows)), dim3(256), 0, st, in, rows, partial);
-  SNERF_LAUNCH_CHECK();
-  return 0;
-}
-
-// d loss / d t[n][c] = sum_s dfa[(n*S+s)][col0 + c]   (gradient reaching the nn.Embedding rows)
-__global__ void ray_sum_kernel(const float* __restrict__ dfa, int ld, int col0, int N, int S, int tau,
-                               float* __restrict__ out) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= N * tau) return;
-  const int n = g / tau, c = g - n * tau;
-  const float* p = dfa + (size_t)n * S * ld + col0 + c;
-  float s = 0.f;
-  for (int j = 0; j < S; ++j) s += p[(size_t)j * ld];
-  out[g] = s;
-}
-
-int launch_ray_sum(const float* dfa, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(ray_sum_kernel, dim3((N * tau + 255) / 256), dim3(256), 0, st, dfa, ld, col0, N, S, tau, out);
-  SNERF_LAUNCH_CHECK();
-  return 0;
-}
 
 }  // namespace snerf

@@ -13,6 +13,10 @@
 //     row block next to a loud one keeps its own 22 bits.  A consumer contracts hi hi + hi lo + lo hi on
 //     v_mfma_f32_32x32x16_f16 (dropped lo lo term: 2^-22 relative) and, where the exponent changes along its
 //     contraction axis, rescales its fp32 accumulators by the power of two (exact).
+// ONE-PLANE form (SNERF_FLAG_F16X1, the reduced-precision mode of the reference's `precision = 16` runs): the same layout with the
+// lo plane left out -- row r is ld * 2 bytes, a 16-column group 32 bytes, the weight units 1 KiB -- the same block exponents, ONE
+// product per contraction step.  11 significant bits relative to the block's maximum (fp16 keeps them down to 2^-27 of it).  Every
+// size / offset helper below takes the plane count `pl` (1 or 2); the kernels are templated on it.
 // Weights are packed once per step in MFMA fragment order ("WF16": 2 KiB units of 32 rows x 16 k = [plane][lane][16 B],
 // lane = 32 (k / 8) + slot, slot m holding row wf16_row(m) of the unit: one fragment is one contiguous KiB that a wave
 // loads straight into registers) with one exponent per matrix.
@@ -39,10 +43,10 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB = 0xFFFFFFF0u;   // voffset the buffer bounds check always rejects (loads return 0)
 
 __host__ __device__ inline int ncb_of(int ld) { return (ld + CB - 1) / CB; }
-__host__ __device__ inline size_t plane_bytes(size_t rows, int ld) { return rows * (size_t)ld * 4; }
+__host__ __device__ inline size_t plane_bytes(size_t rows, int ld, int pl = 2) { return rows * (size_t)ld * 2 * pl; }
 __host__ __device__ inline size_t etab_ints(size_t rows, int ld) { return ((rows + RB - 1) / RB) * (size_t)ncb_of(ld); }
-// byte offset of column k's hi element inside a row (lo: + 32)
-__host__ __device__ inline unsigned g16_off(int k) { return (unsigned)(k >> 4) * 64u + (unsigned)(k & 15) * 2u; }
+// byte offset of column k's hi element inside a row (lo, two planes: + 32)
+__host__ __device__ inline unsigned g16_off(int k, int pl = 2) { return (unsigned)(k >> 4) * 32u * (unsigned)pl + (unsigned)(k & 15) * 2u; }
 
 // exponent for a block whose |max| has these float bits: max * 2^e in [2^13, 2^14); 0 for an empty / non-finite block
 __host__ __device__ inline int exp_of_maxbits(unsigned b) {
@@ -74,6 +78,21 @@ __device__ __forceinline__ void split8(const float (&x)[8], float scale, u32x4& 
   }
   hi = u32x4{h[0], h[1], h[2], h[3]};
   lo = u32x4{l[0], l[1], l[2], l[3]};
+}
+// one plane: hi only
+__device__ __forceinline__ void cvt8(const float (&x)[8], float scale, u32x4& hi) {
+  unsigned h[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h[i]) : "v"(x[2 * i]), "v"(scale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h[i]) : "v"(x[2 * i + 1]), "v"(scale));
+  }
+  hi = u32x4{h[0], h[1], h[2], h[3]};
+}
+__device__ __forceinline__ void join8_1(const u32x4 hi, float inv_scale, float (&x)[8]) {
+  const f16x8 h = __builtin_bit_cast(f16x8, hi);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = (float)h[i] * inv_scale;
 }
 // the inverse: 8 hi + 8 lo fp16 -> fp32 (hi + lo) * inv_scale
 __device__ __forceinline__ void join8(const u32x4 hi, const u32x4 lo, float inv_scale, float (&x)[8]) {
@@ -115,6 +134,7 @@ struct KcArgs {
   int rev = 0;                       // walk the tiles of every XCD group backwards (tiles.h)
   int dbg = 0;                       // diagnostic builds only (bsp_kc.hip: DIAG); ignored by the product kernels
   int* tile_ctr = nullptr;           // 8 zeroed ints (one 64-byte slot per launch): tiles beyond the first are drawn from them; null: fixed shares
+  int pl = 2;                        // planes of EVERY plane tensor of the launch (A, A2, W pack, C, H): 2 (default arithmetic) or 1
 };
 // sign word of (32-row block, 64-column group, lane) of a tensor with `ld` columns: bit 8 ps + c <-> row (lane >> 3) + 8 ps,
 // column 8 (lane & 7) + c of that block (the epilogue's own lane mapping, so producer and consumer touch one word per lane)
@@ -128,6 +148,7 @@ struct DwArgs {
   float* C = nullptr; int ldc = 0;           // fp32 slabs [n_split][slab_stride], row i at i * ldc
   int k_split = 0, n_split = 1; unsigned long long slab_stride = 0;   // k_split % 128 == 0
   int tiles_i = 0, tiles_j = 0;
+  int pl = 2;                        // planes of A and B
 };
 
 int launch_kc(const KcArgs& a, hipStream_t st);          // 128 x 256 tiles, BSP output
@@ -137,8 +158,8 @@ int launch_dw(const DwArgs& a, bool narrow_i, hipStream_t st);   // 256 x 256 ti
 
 // ---- producers / converters (bsp_aux.hip) ------------------------------------------------------------------------------
 // fp32 [rows][ld_src] (cols valid) -> BSP planes + exponents (block maxima taken over the valid rows / columns)
-int launch_to_planes(const float* src, int ld_src, int rows, int cols, char* dst, int* E, int ld, int col0, hipStream_t st);
-int launch_from_planes(const char* src, const int* E, int ld, int col0, int rows, int cols, float* dst, int ld_dst, hipStream_t st);
+int launch_to_planes(const float* src, int ld_src, int rows, int cols, char* dst, int* E, int ld, int col0, int pl, hipStream_t st);
+int launch_from_planes(const char* src, const int* E, int ld, int col0, int rows, int cols, float* dst, int ld_dst, int pl, hipStream_t st);
 
 struct WPackJob {        // one weight operand: fp32 master matrix (possibly read transposed) -> WF16 pack
   unsigned long long src_off;   // float offset of the matrix in the packed fp32 region
@@ -153,18 +174,18 @@ constexpr int WPACK_MAX = 48;
 struct WPackTable { WPackJob j[WPACK_MAX]; int n; };      // host-side table
 constexpr int WPACK_CHUNK = 24;
 struct WPackChunk { WPackJob j[WPACK_CHUNK]; int n; };   // what one launch carries as its argument
-__host__ __device__ inline size_t wp16_bytes(int rows, int K) { return (size_t)((rows + 31) / 32) * (size_t)(K / 16) * 2048; }
-int launch_wpack(const WPackTable& tb, const float* master, char* planes, int* exps, unsigned* maxbits, hipStream_t st);
+__host__ __device__ inline size_t wp16_bytes(int rows, int K, int pl = 2) { return (size_t)((rows + 31) / 32) * (size_t)(K / 16) * 1024 * pl; }
+int launch_wpack(const WPackTable& tb, const float* master, char* planes, int* exps, unsigned* maxbits, int pl, hipStream_t st);
 
 }  // namespace bsp
 struct EncodeArgs;
 namespace bsp {
 // x = o + d z, gamma(x) (or raw x) as planes [P][Ep]; the [sun | t | t_s] block as columns [fa_col0, +16) of the [P][FA] tensor
-int launch_encode_bsp(const EncodeArgs& a, char* pe, int* Epe, char* fa, int* Efa, int fa_col0, hipStream_t st);
+int launch_encode_bsp(const EncodeArgs& a, char* pe, int* Epe, char* fa, int* Efa, int fa_col0, int pl, hipStream_t st);
 int launch_zero_cols(char* base, size_t pitch, size_t width_bytes, int rows, hipStream_t st);   // width_bytes % 16 == 0
-int launch_ray_sum_bsp(const char* dfa, const int* E, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st);
+int launch_ray_sum_bsp(const char* dfa, const int* E, int ld, int col0, int N, int S, int tau, float* out, int pl, hipStream_t st);
 // [rows][32] fp32 -> 256-row partial column sums (+ planes [rows][32] and one exponent per 128 rows when planes != null)
-int launch_colsum32_bsp(const float* in, int rows, float* partial, char* planes, int* E, hipStream_t st);
+int launch_colsum32_bsp(const float* in, int rows, float* partial, char* planes, int* E, int pl, hipStream_t st);
 
 }  // namespace bsp
 }  // namespace snerf

@@ -18,7 +18,7 @@ __device__ __forceinline__ float block_max_256(float m, float* sm) {   // |max| 
 
 // ---- fp32 -> planes: one workgroup per (128-row, 128-column) block ----------------------------------------------------
 __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict__ src, int ld_src, int rows, int cols,
-                                                        char* __restrict__ dst, int* __restrict__ E, int ld, int col0) {
+                                                        char* __restrict__ dst, int* __restrict__ E, int ld, int col0, int pl) {
   __shared__ float sm[4];
   const int rb = blockIdx.y, cb = blockIdx.x;
   const int t = threadIdx.x, c8 = cb * 128 + (t & 15) * 8;
@@ -45,37 +45,37 @@ __global__ __launch_bounds__(256) void to_planes_kernel(const float* __restrict_
     if (r >= rows) continue;
     u32x4 hi, lo;
     split8(v[i], sc, hi, lo);
-    char* d = dst + (size_t)r * ld * 4 + g16_off(col0 + c8);
+    char* d = dst + (size_t)r * ld * 2 * pl + g16_off(col0 + c8, pl);
     *reinterpret_cast<u32x4*>(d) = hi;
-    *reinterpret_cast<u32x4*>(d + 32) = lo;
+    if (pl == 2) *reinterpret_cast<u32x4*>(d + 32) = lo;
   }
 }
 
-int launch_to_planes(const float* src, int ld_src, int rows, int cols, char* dst, int* E, int ld, int col0, hipStream_t st) {
-  if (!src || !dst || !E || rows <= 0 || cols <= 0 || (ld & 15) || (col0 & 127) || col0 + cols > ld) {
+int launch_to_planes(const float* src, int ld_src, int rows, int cols, char* dst, int* E, int ld, int col0, int pl, hipStream_t st) {
+  if (!src || !dst || !E || rows <= 0 || cols <= 0 || (ld & 15) || (col0 & 127) || col0 + cols > ld || pl < 1 || pl > 2) {
     set_error("to_planes: bad argument (ld % 16, col0 % 128)");
     return SNERF_ERR_BAD_DESC;
   }
   hipLaunchKernelGGL(to_planes_kernel, dim3((cols + 127) / 128, (rows + 127) / 128), dim3(256), 0, st, src, ld_src, rows, cols,
-                     dst, E, ld, col0);
+                     dst, E, ld, col0, pl);
   SNERF_LAUNCH_CHECK();
   return SNERF_OK;
 }
 
 __global__ void from_planes_kernel(const char* __restrict__ src, const int* __restrict__ E, int ld, int col0, int rows, int cols,
-                                   float* __restrict__ dst, int ld_dst) {
+                                   float* __restrict__ dst, int ld_dst, int pl) {
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= (size_t)rows * cols) return;
   const int r = (int)(g / cols), c = (int)(g - (size_t)r * cols);
-  const char* p = src + (size_t)r * ld * 4 + g16_off(col0 + c);
-  const float hi = (float)*reinterpret_cast<const _Float16*>(p), lo = (float)*reinterpret_cast<const _Float16*>(p + 32);
+  const char* p = src + (size_t)r * ld * 2 * pl + g16_off(col0 + c, pl);
+  const float hi = (float)*reinterpret_cast<const _Float16*>(p), lo = pl == 2 ? (float)*reinterpret_cast<const _Float16*>(p + 32) : 0.f;
   const int e = E[(size_t)(r >> 7) * ncb_of(ld) + ((col0 + c) >> 7)];
   dst[(size_t)r * ld_dst + c] = __builtin_amdgcn_ldexpf(hi + lo, -e);
 }
 
-int launch_from_planes(const char* src, const int* E, int ld, int col0, int rows, int cols, float* dst, int ld_dst, hipStream_t st) {
+int launch_from_planes(const char* src, const int* E, int ld, int col0, int rows, int cols, float* dst, int ld_dst, int pl, hipStream_t st) {
   const size_t n = (size_t)rows * cols;
-  hipLaunchKernelGGL(from_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, E, ld, col0, rows, cols, dst, ld_dst);
+  hipLaunchKernelGGL(from_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, E, ld, col0, rows, cols, dst, ld_dst, pl);
   SNERF_LAUNCH_CHECK();
   return SNERF_OK;
 }
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void wmax_kernel(WPackChunk tb, const float* _
 }
 
 __global__ __launch_bounds__(256) void wpack_kernel(WPackChunk tb, const float* __restrict__ master, char* __restrict__ planes,
-                                                    int* __restrict__ exps, const unsigned* __restrict__ maxbits) {
+                                                    int* __restrict__ exps, const unsigned* __restrict__ maxbits, int pl) {
   const WPackJob j = tb.j[blockIdx.y];
   const int rb32 = (j.rows + 31) >> 5, nks = j.K >> 4;
   const int e = exp_of_maxbits(maxbits[j.e_idx]);
@@ -119,13 +119,13 @@ __global__ __launch_bounds__(256) void wpack_kernel(WPackChunk tb, const float* 
     const _Float16 h0 = (_Float16)(x[0] * sc), h1 = (_Float16)(x[1] * sc);
     const _Float16 l0 = (_Float16)(x[0] * sc - (float)h0), l1 = (_Float16)(x[1] * sc - (float)h1);
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-    char* u = planes + j.dst_off + (size_t)unit * 2048 + (32 * (kp >> 3) + r) * 16 + (kp & 7) * 2;
+    char* u = planes + j.dst_off + (size_t)unit * 1024 * pl + (32 * (kp >> 3) + r) * 16 + (kp & 7) * 2;   // one plane: 1 KiB units
     *reinterpret_cast<f16x2*>(u) = f16x2{h0, h1};
-    *reinterpret_cast<f16x2*>(u + 1024) = f16x2{l0, l1};
+    if (pl == 2) *reinterpret_cast<f16x2*>(u + 1024) = f16x2{l0, l1};
   }
 }
 
-int launch_wpack(const WPackTable& tb, const float* master, char* planes, int* exps, unsigned* maxbits, hipStream_t st) {
+int launch_wpack(const WPackTable& tb, const float* master, char* planes, int* exps, unsigned* maxbits, int pl, hipStream_t st) {
   if (tb.n <= 0) return SNERF_OK;
   { int rc = launch_zero_bytes(maxbits, WPACK_MAX * sizeof(unsigned), st); if (rc) return rc; }
   // the table travels in chunks of WPACK_CHUNK jobs: by-value kernel arguments beyond ~2 KB did not survive capture in a HIP
@@ -136,7 +136,7 @@ int launch_wpack(const WPackTable& tb, const float* master, char* planes, int* e
       c.n = tb.n - first < WPACK_CHUNK ? tb.n - first : WPACK_CHUNK;
       for (int i = 0; i < c.n; ++i) c.j[i] = tb.j[first + i];
       if (pass == 0) hipLaunchKernelGGL(wmax_kernel, dim3(32, c.n), dim3(256), 0, st, c, master, maxbits);
-      else hipLaunchKernelGGL(wpack_kernel, dim3(128, c.n), dim3(256), 0, st, c, master, planes, exps, maxbits);
+      else hipLaunchKernelGGL(wpack_kernel, dim3(128, c.n), dim3(256), 0, st, c, master, planes, exps, maxbits, pl);
       SNERF_LAUNCH_CHECK();
     }
   return SNERF_OK;
@@ -188,6 +188,7 @@ struct EncodeBsp {
   EncodeArgs a;                 // pe / fa fields unused here
   char* pe; int* Epe;           // planes [P][Ep]
   char* fa; int* Efa; int fa_col0;   // extras columns [fa_col0, fa_col0 + 16) of the [P][FA] tensor (fa may be null)
+  int pl;                       // planes (bsp.h)
 };
 
 __global__ __launch_bounds__(256) void encode_bsp_kernel(EncodeBsp g) {
@@ -243,13 +244,13 @@ __global__ __launch_bounds__(256) void encode_bsp_kernel(EncodeBsp g) {
         }
         v[j] = r;
       }
-      d = g.pe + (size_t)point * a.Ep * 4 + (size_t)grp * 64;
+      d = g.pe + (size_t)point * a.Ep * 2 * g.pl + (size_t)grp * 32 * g.pl;
       sc = s_pe;
     } else {
       const int n = (int)(point / a.S);
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = extras_value(a, n, j);
-      d = g.fa + (size_t)point * a.FA * 4 + g16_off(g.fa_col0);
+      d = g.fa + (size_t)point * a.FA * 2 * g.pl + g16_off(g.fa_col0, g.pl);
       sc = s_x;
     }
     u32x4 hi, lo;
@@ -260,17 +261,17 @@ __global__ __launch_bounds__(256) void encode_bsp_kernel(EncodeBsp g) {
       for (int j = 0; j < 8; ++j) h8[j] = v[8 * half + j];
       split8(h8, sc, hi, lo);
       *reinterpret_cast<u32x4*>(d + 16 * half) = hi;
-      *reinterpret_cast<u32x4*>(d + 32 + 16 * half) = lo;
+      if (g.pl == 2) *reinterpret_cast<u32x4*>(d + 32 + 16 * half) = lo;
     }
   }
 }
 
-int launch_encode_bsp(const EncodeArgs& a, char* pe, int* Epe, char* fa, int* Efa, int fa_col0, hipStream_t st) {
+int launch_encode_bsp(const EncodeArgs& a, char* pe, int* Epe, char* fa, int* Efa, int fa_col0, int pl, hipStream_t st) {
   if (a.Ep > 128 || (a.Ep & 15) || (fa && ((fa_col0 & 127) || (a.FA & 15) || a.Xp != 16))) {
     set_error("encode: Ep <= 128, Ep % 16 == 0, extras block of 16 columns at a multiple of 128");
     return SNERF_ERR_BAD_DESC;
   }
-  EncodeBsp g{a, pe, Epe, fa, Efa, fa_col0};
+  EncodeBsp g{a, pe, Epe, fa, Efa, fa_col0, pl};
   const long long P = (long long)a.N * a.S;
   hipLaunchKernelGGL(encode_bsp_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), 0, st, g);
   SNERF_LAUNCH_CHECK();
@@ -279,24 +280,24 @@ int launch_encode_bsp(const EncodeArgs& a, char* pe, int* Epe, char* fa, int* Ef
 
 // ---- d loss / d t[n][c] = sum_s dfa[(n S + s)][col0 + c] from planes -------------------------------------------------
 __global__ void ray_sum_bsp_kernel(const char* __restrict__ dfa, const int* __restrict__ E, int ld, int col0, int N, int S, int tau,
-                                   float* __restrict__ out) {
+                                   float* __restrict__ out, int pl) {
   const int gi = blockIdx.x * blockDim.x + threadIdx.x;
   if (gi >= N * tau) return;
   const int n = gi / tau, c = gi - n * tau;
   const int ncb = ncb_of(ld), cb = (col0 + c) >> 7;
-  const unsigned co = g16_off(col0 + c);
+  const unsigned co = g16_off(col0 + c, pl);
   float s = 0.f;
   for (int j = 0; j < S; ++j) {
     const size_t p = (size_t)n * S + j;
-    const char* q = dfa + p * ld * 4 + co;
-    const float v = (float)*reinterpret_cast<const _Float16*>(q) + (float)*reinterpret_cast<const _Float16*>(q + 32);
+    const char* q = dfa + p * ld * 2 * pl + co;
+    const float v = (float)*reinterpret_cast<const _Float16*>(q) + (pl == 2 ? (float)*reinterpret_cast<const _Float16*>(q + 32) : 0.f);
     s += __builtin_amdgcn_ldexpf(v, -E[(p >> 7) * ncb + cb]);
   }
   out[gi] = s;
 }
 
-int launch_ray_sum_bsp(const char* dfa, const int* E, int ld, int col0, int N, int S, int tau, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(ray_sum_bsp_kernel, dim3((N * tau + 255) / 256), dim3(256), 0, st, dfa, E, ld, col0, N, S, tau, out);
+int launch_ray_sum_bsp(const char* dfa, const int* E, int ld, int col0, int N, int S, int tau, float* out, int pl, hipStream_t st) {
+  hipLaunchKernelGGL(ray_sum_bsp_kernel, dim3((N * tau + 255) / 256), dim3(256), 0, st, dfa, E, ld, col0, N, S, tau, out, pl);
   SNERF_LAUNCH_CHECK();
   return SNERF_OK;
 }
@@ -304,7 +305,7 @@ int launch_ray_sum_bsp(const char* dfa, const int* E, int ld, int col0, int N, i
 // ---- 32-wide head gradients: column sums (bias gradients) and the planes the dX / dW GEMMs read, in one pass ---------
 // [rows][32] fp32 -> partial[blocks][32] (256 rows per block) + planes [rows][32] with one exponent per 128 rows
 __global__ __launch_bounds__(256) void colsum32_bsp_kernel(const float* __restrict__ in, int rows, float* __restrict__ partial,
-                                                           char* __restrict__ pl, int* __restrict__ E) {
+                                                           char* __restrict__ pl, int* __restrict__ E, int npl) {
   __shared__ float4 sm[32][8];
   __shared__ float smx[2][2];
   const int c4 = threadIdx.x & 7, rg = threadIdx.x >> 3;   // 32 row groups x 8 column quads; row = r0 + rg + 32 i
@@ -356,14 +357,14 @@ __global__ __launch_bounds__(256) void colsum32_bsp_kernel(const float* __restri
     f16x4 h, l;
 #pragma unroll
     for (int c = 0; c < 4; ++c) { h[c] = (_Float16)x[c]; l[c] = (_Float16)(x[c] - (float)h[c]); }
-    char* d = pl + (size_t)r * 128 + g16_off(4 * c4);
+    char* d = pl + (size_t)r * 64 * npl + g16_off(4 * c4, npl);
     *reinterpret_cast<f16x4*>(d) = h;
-    *reinterpret_cast<f16x4*>(d + 32) = l;
+    if (npl == 2) *reinterpret_cast<f16x4*>(d + 32) = l;
   }
 }
 
-int launch_colsum32_bsp(const float* in, int rows, float* partial, char* planes, int* E, hipStream_t st) {
-  hipLaunchKernelGGL(colsum32_bsp_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, in, rows, partial, planes, E);
+int launch_colsum32_bsp(const float* in, int rows, float* partial, char* planes, int* E, int pl, hipStream_t st) {
+  hipLaunchKernelGGL(colsum32_bsp_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, in, rows, partial, planes, E, pl);
   SNERF_LAUNCH_CHECK();
   return SNERF_OK;
 }

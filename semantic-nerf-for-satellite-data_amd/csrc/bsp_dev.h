@@ -66,10 +66,10 @@ __device__ __forceinline__ float absmax3(float a, float b, float m) {
 }
 
 // exponent of k-step s of a K-contiguous A operand made of one or two segments (any lane; uniform inputs)
-__device__ __forceinline__ int kc_exp_of_step(const KcArgs& p, int rb, int s, int nks1) {
+__device__ __forceinline__ int kc_exp_of_step(const KcArgs& p, int rb, int s, int nks1, int ksub = 16) {
   const bool seg2 = s >= nks1;   // branch-free: one load through a selected pointer
   const int* E = seg2 ? p.EA2 : p.EA;
-  const int ld = seg2 ? p.lda2 : p.lda, col = seg2 ? p.a2_col0 + 16 * (s - nks1) : p.a_col0 + 16 * s;
+  const int ld = seg2 ? p.lda2 : p.lda, col = seg2 ? p.a2_col0 + ksub * (s - nks1) : p.a_col0 + ksub * s;
   return E[(size_t)rb * ncb_of(ld) + (col >> 7)];
 }
 

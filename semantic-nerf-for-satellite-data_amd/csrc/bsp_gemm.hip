@@ -31,22 +31,27 @@ namespace bsp {
 constexpr int KC_STRIP = 32 * 68 * 4;                      // one wave's 32 x (64 + 4) fp32 transposition strip (dW epilogue)
 constexpr int KN_A = 128 * 64, KN_RING = 4, KN_TAIL = KN_RING * KN_A, KN_LDS = KN_TAIL + 512;
 
+// PL (planes, bsp.h): a step is 64 bytes of every A row = 16 k of two planes (three products) or 32 k of one plane (two MFMAs on
+// two 16-k weight units).
+template <int PL>
 __global__ __launch_bounds__(256, 4) void gemm_kcn_kernel(const KcArgs p) {
+  constexpr int EB = 2 * PL, KSUB = PL == 2 ? 16 : 32, KSH = PL == 2 ? 4 : 5;
   __shared__ __attribute__((aligned(16))) char lds[KN_LDS];
   int* etab = reinterpret_cast<int*>(lds + KN_TAIL);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int ti = blockIdx.x, i0 = ti * 128, wi0 = wave * 32;
-  const int nks = p.K >> 4, nks1 = p.Ka >> 4;
-  const srd_t srdA = make_srd(p.A + ((size_t)i0 * p.lda + p.a_col0) * 4,
-                              clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda + p.Ka) * 4ull : 0ull));
+  const int nks16 = p.K >> 4;
+  const int nks = (p.K + KSUB - 1) >> KSH, nks1 = nks;      // one segment (launch_kc_narrow); one plane: the last step may be half empty
+  const srd_t srdA = make_srd(p.A + ((size_t)i0 * p.lda + p.a_col0) * EB,
+                              clamp_bytes(i0 < p.I ? ((unsigned long long)(p.I - i0 - 1) * p.lda + p.Ka) * (unsigned long long)EB : 0ull));
   const srd_t srdW = make_srd(p.W, p.w_bytes);
   unsigned voA[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int row = 64 * q + (t >> 2);
     const unsigned c = (unsigned)((t & 3) ^ ((row >> 2) & 3));
-    voA[q] = (i0 + row < p.I) ? (unsigned)row * (unsigned)p.lda * 4u + 16u * c : OOB;
+    voA[q] = (i0 + row < p.I) ? (unsigned)row * (unsigned)p.lda * (unsigned)EB + 16u * c : OOB;
   }
   const unsigned w_u0 = (unsigned)(p.w_row0 >> 5), w_ks0 = (unsigned)(p.w_k0 >> 4);
   auto issueA = [&](int s, int slot) {
@@ -55,17 +60,23 @@ __global__ __launch_bounds__(256, 4) void gemm_kcn_kernel(const KcArgs p) {
   };
   struct BFrag { u32x4 h, l; };
   auto loadB = [&](int s, BFrag& b) {
-    const unsigned so = ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_u0) * 2048u;
-    const unsigned vo = s < nks ? 16u * (unsigned)lane : OOB;
-    b.h = __builtin_amdgcn_raw_buffer_load_b128(srdW, vo, so, 0);
-    b.l = __builtin_amdgcn_raw_buffer_load_b128(srdW, vo == OOB ? OOB : vo + 1024u, so, 0);
+    if constexpr (PL == 2) {
+      const unsigned so = ((w_ks0 + (unsigned)s) * (unsigned)p.w_rb32 + w_u0) * 2048u;
+      const unsigned vo = s < nks ? 16u * (unsigned)lane : OOB;
+      b.h = __builtin_amdgcn_raw_buffer_load_b128(srdW, vo, so, 0);
+      b.l = __builtin_amdgcn_raw_buffer_load_b128(srdW, vo == OOB ? OOB : vo + 1024u, so, 0);
+    } else {   // 1 KiB units: h = the first 16 k of the step, l = the second
+      const unsigned so = ((w_ks0 + 2u * (unsigned)s) * (unsigned)p.w_rb32 + w_u0) * 1024u;
+      b.h = __builtin_amdgcn_raw_buffer_load_b128(srdW, 2 * s < nks16 ? 16u * (unsigned)lane : OOB, so, 0);
+      b.l = __builtin_amdgcn_raw_buffer_load_b128(srdW, 2 * s + 1 < nks16 ? 16u * (unsigned)lane : OOB, so + (unsigned)p.w_rb32 * 1024u, 0);
+    }
   };
   const int sA = lane, sB = lane + 64;
-  const int eA = sA < nks ? kc_exp_of_step(p, ti, sA, nks1) : 0;
-  const int eB = sB < nks ? kc_exp_of_step(p, ti, sB, nks1) : 0;
-  const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti, sA - 1, nks1) : eA;
-  const int eBp = sB < nks ? kc_exp_of_step(p, ti, sB - 1, nks1) : eB;
-  const int e_last = kc_exp_of_step(p, ti, nks - 1, nks1);
+  const int eA = sA < nks ? kc_exp_of_step(p, ti, sA, nks1, KSUB) : 0;
+  const int eB = sB < nks ? kc_exp_of_step(p, ti, sB, nks1, KSUB) : 0;
+  const int eAp = (sA > 0 && sA < nks) ? kc_exp_of_step(p, ti, sA - 1, nks1, KSUB) : eA;
+  const int eBp = sB < nks ? kc_exp_of_step(p, ti, sB - 1, nks1, KSUB) : eB;
+  const int e_last = kc_exp_of_step(p, ti, nks - 1, nks1, KSUB);
   issueA(0, 0);
   BFrag bq0, bq1;
   loadB(0, bq0);
@@ -85,7 +96,12 @@ __global__ __launch_bounds__(256, 4) void gemm_kcn_kernel(const KcArgs p) {
     loadB(s + 1, bn);
     issueA(s + 2, (slot + 2) % KN_RING);
     const char* st = lds + slot * KN_A;
-    acc = mfma3(ldsfrag(st + wi0 * 64 + fo0), ldsfrag(st + wi0 * 64 + fo1), __builtin_bit_cast(f16x8, bc.h), __builtin_bit_cast(f16x8, bc.l), acc);
+    if constexpr (PL == 2) {
+      acc = mfma3(ldsfrag(st + wi0 * 64 + fo0), ldsfrag(st + wi0 * 64 + fo1), __builtin_bit_cast(f16x8, bc.h), __builtin_bit_cast(f16x8, bc.l), acc);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ldsfrag(st + wi0 * 64 + fo0), __builtin_bit_cast(f16x8, bc.h), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ldsfrag(st + wi0 * 64 + fo1), __builtin_bit_cast(f16x8, bc.l), acc, 0, 0, 0);
+    }
   };
   for (int s = 0; s < nks; s += 4) {
     step(s, 0, bq0, bq1);
@@ -108,11 +124,17 @@ __global__ __launch_bounds__(256, 4) void gemm_kcn_kernel(const KcArgs p) {
 // dW = dZ^T X: both operands point-contiguous BSP, transposed fragment reads, split-K slabs in fp32
 // ------------------------------------------------------------------------------------------------------------------
 // TI = 256: 512 threads, eight waves of 128 x 64 (2 x 4), one workgroup per CU.  TI = 32: 256 threads, four waves of 32 x 64.
-template <int TI> struct DwCfg {
+// PL (planes, bsp.h): one plane halves the bytes of a point row, so a stage of the SAME bytes is 32 points deep instead of 16 --
+// the same DMA requests and fragment reads per stage, 16 MFMAs (two 16-point steps, one product) instead of 24.
+template <int TI, int PL> struct DwCfg {
   static constexpr int NTH = TI == 256 ? 512 : 256, WAVES = NTH / 64;
   static constexpr int MI = TI == 256 ? 4 : 1;                   // 32-row blocks per wave along i
-  static constexpr int A_PITCH = TI * 4;                         // bytes of one point row of the A stage (TI columns, both planes)
-  static constexpr int A_BYTES = 16 * A_PITCH, B_BYTES = 16 * 1024, STAGE = A_BYTES + B_BYTES, RING = 3;   // stages in the ring, RING - 1 in flight (four: measured equal, 326 vs 327 us)
+  static constexpr int EB = 2 * PL;                              // bytes per element
+  static constexpr int PTS = PL == 2 ? 16 : 32;                  // points per stage
+  static constexpr int SPC = 128 / PTS;                          // stages per 128-point exponent chunk
+  static constexpr int A_PITCH = TI * EB;                        // bytes of one point row of the A stage (TI columns, all planes)
+  static constexpr int B_PITCH = 256 * EB;
+  static constexpr int A_BYTES = PTS * A_PITCH, B_BYTES = PTS * B_PITCH, STAGE = A_BYTES + B_BYTES, RING = 3;   // stages in the ring, RING - 1 in flight (four: measured equal, 326 vs 327 us)
   static constexpr int STRIPS = WAVES * KC_STRIP;
   static constexpr int TAIL = (RING * STAGE > STRIPS) ? RING * STAGE : STRIPS;
   static constexpr int MAXCH = 128;                              // 128-point chunks per split (k_split <= 16384)
@@ -121,13 +143,15 @@ template <int TI> struct DwCfg {
 };
 // byte swizzle of point row p inside a stage: 1 KiB rows put the four rows of a transposed-read block into four bank
 // quarters; the 128-byte rows of the 32-column form need only the hi/lo flip of the upper two rows
+// (one plane: 512-byte rows -- two bank rows each -- take all four 32-byte slots of a 128-byte span; 64-byte rows need nothing)
 template <int PITCH> __device__ __forceinline__ unsigned dw_swz(int p) {
-  return PITCH == 1024 ? (unsigned)(((p & 1) << 5) | ((p & 2) << 6)) : (unsigned)((p & 2) << 4);
+  return PITCH == 1024 ? (unsigned)(((p & 1) << 5) | ((p & 2) << 6)) : (PITCH == 512 ? (unsigned)((p & 3) << 5) : (PITCH == 128 ? (unsigned)((p & 2) << 4) : 0u));
 }
 
-template <int TI>
-__global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_kernel(const DwArgs p) {
-  using T = DwCfg<TI>;
+template <int TI, int PL>
+__global__ __launch_bounds__(TI == 256 ? 512 : 256, 2) void gemm_dw_kernel(const DwArgs p) {
+  using T = DwCfg<TI, PL>;
+  constexpr int EB = T::EB, PTS = T::PTS;
   __shared__ __attribute__((aligned(16))) char lds[T::LDS];
   int* esum = reinterpret_cast<int*>(lds + T::TAIL);       // [wave][chunk]: exponent of dZ block + exponent of X block
 
@@ -139,48 +163,51 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
   const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
   const int i0 = ti * TI, j0 = tj * 256;
   const int kBeg = split * p.k_split, kEnd = min(p.P, kBeg + p.k_split);
-  const int nks = (kEnd - kBeg + 15) >> 4;
+  const int nks = (kEnd - kBeg + PTS - 1) / PTS;
   float* C = p.C + (size_t)split * p.slab_stride;
 
   // ---- DMA sources: a piece is 1 KiB = one point row of the 256-column operand (eight 128-byte rows of the 32-column one)
-  const srd_words srdA = make_srd_words(p.A + ((size_t)kBeg * p.lda + p.a_col0 + i0) * 4,
-                                        clamp_bytes(kEnd > kBeg ? ((unsigned long long)(kEnd - kBeg) * p.lda - (p.a_col0 + i0)) * 4ull : 0ull));
-  const srd_words srdB = make_srd_words(p.B + ((size_t)kBeg * p.ldb + p.b_col0 + j0) * 4,
-                                        clamp_bytes(kEnd > kBeg ? ((unsigned long long)(kEnd - kBeg) * p.ldb - (p.b_col0 + j0)) * 4ull : 0ull));
+  const srd_words srdA = make_srd_words(p.A + ((size_t)kBeg * p.lda + p.a_col0 + i0) * EB,
+                                        clamp_bytes(kEnd > kBeg ? ((unsigned long long)(kEnd - kBeg) * p.lda - (p.a_col0 + i0)) * (unsigned long long)EB : 0ull));
+  const srd_words srdB = make_srd_words(p.B + ((size_t)kBeg * p.ldb + p.b_col0 + j0) * EB,
+                                        clamp_bytes(kEnd > kBeg ? ((unsigned long long)(kEnd - kBeg) * p.ldb - (p.b_col0 + j0)) * (unsigned long long)EB : 0ull));
   const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(lds));
-  constexpr int PA = T::A_PITCH;
+  constexpr int PA = T::A_PITCH, PB = T::B_PITCH;
   constexpr int A_PIECES = T::A_BYTES / 1024;                         // 16 (TI = 256) or 2 (TI = 32)
   constexpr int NPA = (A_PIECES + T::WAVES - 1) / T::WAVES;           // A pieces per wave: 2 / 1 (waves >= 2 of the narrow form: a rejected one)
   constexpr int NPB = 16 / T::WAVES;                                  // B pieces per wave: 2 / 4
+  constexpr int RPA = PA >= 1024 ? 1 : 1024 / PA, RPB = 1024 / PB;    // point rows per 1 KiB piece
+  constexpr int LRA = 64 / RPA, LRB = 64 / RPB;                       // lanes per point row
   unsigned voA[NPA], voB[NPB];
   int prA[NPA], prB[NPB];        // point row (inside the stage) each piece's lane belongs to
 #pragma unroll
   for (int q = 0; q < NPA; ++q) {
     const int piece = wave * NPA + q;
-    const int pr = PA == 1024 ? piece : piece * 8 + (lane >> 3);
-    const unsigned byte = PA == 1024 ? 16u * lane : 16u * (lane & 7);
+    const int pr = piece * RPA + lane / LRA;
+    const unsigned byte = 16u * (unsigned)(lane % LRA);
     prA[q] = piece < A_PIECES ? pr : -1;
-    voA[q] = (unsigned)pr * (unsigned)p.lda * 4u + (byte ^ dw_swz<PA>(pr));
+    voA[q] = (unsigned)pr * (unsigned)p.lda * (unsigned)EB + (byte ^ dw_swz<PA>(pr));
   }
 #pragma unroll
   for (int q = 0; q < NPB; ++q) {
-    const int pr = wave * NPB + q;
+    const int piece = wave * NPB + q;
+    const int pr = piece * RPB + lane / LRB;
     prB[q] = pr;
-    voB[q] = (unsigned)pr * (unsigned)p.ldb * 4u + ((16u * lane) ^ dw_swz<1024>(pr));
+    voB[q] = (unsigned)pr * (unsigned)p.ldb * (unsigned)EB + ((16u * (unsigned)(lane % LRB)) ^ dw_swz<PB>(pr));
   }
   auto issue = [&](int s, int slot) {
-    const int prow0 = kBeg + 16 * s;
+    const int prow0 = kBeg + PTS * s;
 #pragma unroll
     for (int q = 0; q < NPA; ++q) {
       const int piece = wave * NPA + q;
       const bool ok = s < nks && prA[q] >= 0 && prow0 + prA[q] < kEnd;
       dma16_asm(srdA, lds0 + (unsigned)(piece < A_PIECES ? slot * T::STAGE + piece * 1024 : T::DUMMY + wave * 1024), ok ? voA[q] : OOB,
-                (unsigned)s * 16u * (unsigned)p.lda * 4u);
+                (unsigned)s * (unsigned)PTS * (unsigned)p.lda * (unsigned)EB);
     }
 #pragma unroll
     for (int q = 0; q < NPB; ++q) {
       const bool ok = s < nks && prow0 + prB[q] < kEnd;
-      dma16_asm(srdB, lds0 + (unsigned)(slot * T::STAGE + T::A_BYTES + prB[q] * 1024), ok ? voB[q] : OOB, (unsigned)s * 16u * (unsigned)p.ldb * 4u);
+      dma16_asm(srdB, lds0 + (unsigned)(slot * T::STAGE + T::A_BYTES + (wave * NPB + q) * 1024), ok ? voB[q] : OOB, (unsigned)s * (unsigned)PTS * (unsigned)p.ldb * (unsigned)EB);
     }
   };
   // ---- exponent sums per 128-point chunk, per wave (its 128-row / 64-column sub-tile lies in one block of either tensor)
@@ -212,8 +239,10 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
   // lane 4 q + pp of the group addresses point row q, columns 4 pp .. 4 pp + 3 (8 bytes)
   const int g = lane >> 4, q4 = (lane >> 2) & 3, pp = lane & 3;
   const int kq = 8 * (g >> 1) + q4;
+  // `pl`: two planes: the plane (hi / lo of the same 16 points); one plane: the first / second 16 points of the 32-point stage
   auto frag_off = [&](int col, int pl, int pitch, unsigned sw) -> unsigned {   // col: first column of the 16-group (% 16 == 0)
-    return (unsigned)kq * (unsigned)pitch + ((((unsigned)(col >> 4) * 64u) + (unsigned)pl * 32u + 8u * (unsigned)pp) ^ sw);
+    if constexpr (PL == 2) return (unsigned)kq * (unsigned)pitch + ((((unsigned)(col >> 4) * 64u) + (unsigned)pl * 32u + 8u * (unsigned)pp) ^ sw);
+    else return (unsigned)(kq + 16 * pl) * (unsigned)pitch + ((((unsigned)(col >> 4) * 32u) + 8u * (unsigned)pp) ^ sw);
   };
   unsigned foA[T::MI][2], foB[2][2];
 #pragma unroll
@@ -223,7 +252,7 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
 #pragma unroll
   for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) foB[nj][pl] = (unsigned)T::A_BYTES + frag_off(wj0 + 32 * nj + 16 * (g & 1), pl, 1024, dw_swz<1024>(q4));
+    for (int pl = 0; pl < 2; ++pl) foB[nj][pl] = (unsigned)T::A_BYTES + frag_off(wj0 + 32 * nj + 16 * (g & 1), pl, PB, dw_swz<PB>(q4));
   typedef __fp16 h4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
   typedef h4_t __attribute__((address_space(3))) * lds4_t;
   auto trfrag = [&](const char* base, unsigned off, int pitch) -> f16x8 {
@@ -239,9 +268,14 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
   // The sum of two exponents can move by more than the accumulators can follow (2^41 x 2^de must stay finite): a chunk more
   // than 2^64 quieter than the frame the accumulators are in adds nothing an fp32 sum could hold next to what is already
   // there -- its weight fragments are zeroed and the frame stays (a lone quiet chunk no longer ends in Inf / NaN gradients).
+  auto mma = [](f16x8 ah, f16x8 al, f16x8 bh, f16x8 bl, f32x16 c) -> f32x16 {
+    if constexpr (PL == 2) return mfma3(ah, al, bh, bl, c);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);      // points 0-15 of the stage
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bl, c, 0, 0, 0);   // points 16-31
+  };
   auto chunk = [&](int s) {
-    if ((s & 7) != 0) return;
-    const int e_new = __builtin_amdgcn_readfirstlane(esum[wave * T::MAXCH + (s >> 3)]);
+    if ((s & (T::SPC - 1)) != 0) return;
+    const int e_new = __builtin_amdgcn_readfirstlane(esum[wave * T::MAXCH + s / T::SPC]);
     quiet = s != 0 && e_new - e_cur > 64;
     if (s == 0) e_cur = e_new;
     else if (__builtin_expect(e_new != e_cur && !quiet, 0)) {
@@ -274,7 +308,7 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
       chunk(s);
       const char* st = lds + slot * T::STAGE;
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) { fb_h[nj] = trfrag(st, foB[nj][0], 1024); fb_l[nj] = trfrag(st, foB[nj][1], 1024); }
+      for (int nj = 0; nj < 2; ++nj) { fb_h[nj] = trfrag(st, foB[nj][0], PB); fb_l[nj] = trfrag(st, foB[nj][1], PB); }
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) { fa_h[mi] = trfrag(st, foA[mi][0], PA); fa_l[mi] = trfrag(st, foA[mi][1], PA); }
       if (__builtin_expect(quiet, 0)) {
@@ -287,7 +321,7 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = mfma3(fa_h[mi], fa_l[mi], fb_h[nj], fb_l[nj], acc[mi][nj]);
+        for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = mma(fa_h[mi], fa_l[mi], fb_h[nj], fb_l[nj], acc[mi][nj]);
       __builtin_amdgcn_s_setprio(0);
     };
     wait_vm<(T::RING - 2) * NPIECE>();      // stage 0 (own pieces); the later ones stay in flight
@@ -325,7 +359,7 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
     const char* st = lds + slot * T::STAGE;
     f16x8 bh[2], bl[2];
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj) { bh[nj] = trfrag(st, foB[nj][0], 1024); bl[nj] = trfrag(st, foB[nj][1], 1024); }
+    for (int nj = 0; nj < 2; ++nj) { bh[nj] = trfrag(st, foB[nj][0], PB); bl[nj] = trfrag(st, foB[nj][1], PB); }
     if (__builtin_expect(quiet, 0)) {
 #pragma unroll
       for (int nj = 0; nj < 2; ++nj) { bh[nj] = f16x8{}; bl[nj] = f16x8{}; }
@@ -334,7 +368,7 @@ __global__ __launch_bounds__(DwCfg<TI>::NTH, TI == 256 ? 2 : 2) void gemm_dw_ker
     for (int mi = 0; mi < T::MI; ++mi) {
       const f16x8 ah = trfrag(st, foA[mi][0], PA), al = trfrag(st, foA[mi][1], PA);
 #pragma unroll
-      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = mfma3(ah, al, bh[nj], bl[nj], acc[mi][nj]);
+      for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = mma(ah, al, bh[nj], bl[nj], acc[mi][nj]);
     }
   };
   for (int s = 0; s < nks; s += 3) {
@@ -384,13 +418,16 @@ static int bad(const char* why) {
 
 int check_kc(const KcArgs& a, bool narrow) {
   if (!a.A || !a.EA || !a.W || !a.EW) return bad("null operand");
+  if (a.pl != 1 && a.pl != 2) return bad("planes: 1 or 2");
+  const int EB = 2 * a.pl, stage = a.pl == 2 ? 32 : 64;     // bytes per element; contraction depth of one LDS stage (128 B per row)
   if (a.I <= 0 || a.J <= 0 || a.K <= 0) return bad("empty problem");
   if ((a.K & 15) || (a.Ka & 15) || a.Ka <= 0 || a.Ka > a.K || a.K > 2048) return bad("K and Ka must be multiples of 16, K <= 2048");
   if ((a.lda & 15) || (a.a_col0 & 15) || a.a_col0 + a.Ka > a.lda) return bad("A segment does not fit its tensor (16-column groups)");
-  if (a.Ka < a.K && (a.Ka & 31)) return bad("two A segments: the first must be a multiple of 32 columns (one LDS stage)");
+  if (a.Ka < a.K && (a.Ka % stage)) return bad("two A segments: the first must be a whole number of LDS stages (32 columns; one plane: 64)");
+  if (a.pl == 1 && ((a.a_col0 & 31) || (a.Ka < a.K && (a.a2_col0 & 31)))) return bad("one plane: A segments start on a multiple of 32 columns");
   if (a.Ka < a.K && (!a.A2 || !a.EA2 || (a.lda2 & 15) || (a.a2_col0 & 15) || a.a2_col0 + (a.K - a.Ka) > a.lda2)) return bad("second A segment");
   if ((a.w_row0 & 31) || (a.w_k0 & 15) || a.w_rb32 <= 0) return bad("weight operand must start on a 32-row / 16-k unit");
-  if ((size_t)128 * (a.lda > a.lda2 ? a.lda : a.lda2) * 4 >= 0x7FFFFFFFull) return bad("leading dimension too large");
+  if ((size_t)128 * (a.lda > a.lda2 ? a.lda : a.lda2) * EB >= 0x7FFFFFFFull) return bad("leading dimension too large");
   if (((uintptr_t)a.A & 15) || ((uintptr_t)a.W & 15) || (a.A2 && ((uintptr_t)a.A2 & 15))) return bad("operands must be 16-byte aligned");
   if (narrow) {
     if (!a.Cf || a.J > 32 || a.Ka != a.K) return bad("narrow variant: fp32 output, J <= 32, one A segment");
@@ -405,7 +442,7 @@ int check_kc(const KcArgs& a, bool narrow) {
     if (a.act != ACT_NONE) return bad("activation and derivative in one epilogue");
   }
   if (a.colsum && (((uintptr_t)a.colsum & 15) || (a.ldcs & 3))) return bad("colsum alignment");
-  if ((size_t)128 * a.ldc * 4 >= 0x7FFFFFFFull) return bad("ldc too large");
+  if ((size_t)128 * a.ldc * EB >= 0x7FFFFFFFull) return bad("ldc too large");
   return SNERF_OK;
 }
 
@@ -416,7 +453,8 @@ int launch_kc_narrow(const KcArgs& a0, hipStream_t st) {
   int rc = check_kc(a, true);
   if (rc) return rc;
   const int tok = prof_hook_begin(2.0 * a.I * 32.0 * a.K, 3, st);
-  hipLaunchKernelGGL(gemm_kcn_kernel, dim3((a.I + 127) / 128), dim3(256), 0, st, a);
+  if (a.pl == 2) hipLaunchKernelGGL(gemm_kcn_kernel<2>, dim3((a.I + 127) / 128), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(gemm_kcn_kernel<1>, dim3((a.I + 127) / 128), dim3(256), 0, st, a);
   SNERF_LAUNCH_CHECK();
   prof_hook_end(tok, st);
   return SNERF_OK;
@@ -428,7 +466,8 @@ int launch_dw(const DwArgs& a0, bool narrow_i, hipStream_t st) {
   if (a.I <= 0 || a.J <= 0 || a.P <= 0) return bad("dW: empty problem");
   if ((a.lda & 15) || (a.ldb & 15) || (a.a_col0 & 15) || (a.b_col0 & 15) || (a.J & 3) || (a.ldc & 3)) return bad("dW: leading dimensions / column offsets");
   if (a.k_split <= 0 || (a.k_split & 127) || a.k_split > 16384 || a.n_split < 1) return bad("dW: k_split must be a multiple of 128, <= 16384");
-  if ((size_t)a.k_split * (a.lda > a.ldb ? a.lda : a.ldb) * 4 >= 0xFFFFFFF0ull) return bad("dW: k_split * ld exceeds the 32-bit span");
+  if (a.pl != 1 && a.pl != 2) return bad("dW: planes: 1 or 2");
+  if ((size_t)a.k_split * (a.lda > a.ldb ? a.lda : a.ldb) * 2 * a.pl >= 0xFFFFFFF0ull) return bad("dW: k_split * ld exceeds the 32-bit span");
   if (narrow_i ? (a.I > 32 || ((a.a_col0 & 127) + 32 > 128)) : ((a.a_col0 & 127) != 0)) return bad("dW: the A columns of a wave must lie in one exponent block");
   if (a.b_col0 & 63) return bad("dW: b_col0 % 64");
   if (((uintptr_t)a.A & 15) || ((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15)) return bad("dW: alignment");
@@ -437,8 +476,8 @@ int launch_dw(const DwArgs& a0, bool narrow_i, hipStream_t st) {
   a.tiles_j = (a.J + 255) / 256;
   const dim3 grid(a.tiles_i * a.tiles_j, 1, a.n_split);
   const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.P, narrow_i ? 3 : 2, st);
-  if (narrow_i) hipLaunchKernelGGL(gemm_dw_kernel<32>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(gemm_dw_kernel<256>, grid, dim3(512), 0, st, a);
+  if (narrow_i) { if (a.pl == 2) hipLaunchKernelGGL((gemm_dw_kernel<32, 2>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((gemm_dw_kernel<32, 1>), grid, dim3(256), 0, st, a); }
+  else { if (a.pl == 2) hipLaunchKernelGGL((gemm_dw_kernel<256, 2>), grid, dim3(512), 0, st, a); else hipLaunchKernelGGL((gemm_dw_kernel<256, 1>), grid, dim3(512), 0, st, a); }
   SNERF_LAUNCH_CHECK();
   prof_hook_end(tok, st);
   return SNERF_OK;

@@ -42,7 +42,11 @@ constexpr int KC_LDS = KC_NEXT + 64;
 // DIAG (tools/ablate/build_diag.sh only; the product instantiates DIAG = false): KcArgs::dbg removes operand traffic through
 // zero-size descriptors -- 1: A, 2: W (host side), 4: stores, 8: every tile reads the first 128 rows of A (always L2-resident).
 // Timing-only: the results are wrong.
-template <int ACT, int AUX, bool COLSUM, bool SIGNS, int SINM, bool DIAG = false>
+// PL = planes per operand / result tensor (bsp.h).  PL = 1: a 16-column group is 32 bytes, so the SAME bytes carry twice the
+// contraction depth -- a "sub-step" below is 64 bytes of every A row = 16 k of two planes (3 products) or 32 k of one plane
+// (1 product per 16 k): same LDS traffic, same request counts, 16 instead of 24 MFMAs per sub-step; a stage (128 bytes per row)
+// is 32 / 64 k deep.
+template <int PL, int ACT, int AUX, bool COLSUM, bool SIGNS, int SINM, bool DIAG = false>
 __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   // The arguments are read from the kernarg segment where they are needed (kargs(): a pointer the compiler must take as
   // new at every use site, so that it re-reads instead of keeping ~50 scalars alive across the k-loop and spilling them).
@@ -53,7 +57,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wj0 = wave * 64;
   const int tiles_i = p->tiles_i, tiles_j = p->tiles_j, ntiles = tiles_i * tiles_j;
-  const int nks = p->K >> 4, nks1 = p->Ka >> 4;
+  constexpr int EB = 2 * PL;                                   // bytes per element of a plane tensor
+  constexpr int KSUB = PL == 2 ? 16 : 32, KSH = PL == 2 ? 4 : 5;  // contraction depth of a sub-step
+  const int nks16 = p->K >> 4;                                 // 16-deep steps of the weight pack
+  const int nks = (p->K + KSUB - 1) >> KSH;                    // sub-steps (one plane: the last one may be half empty: K % 32 == 16)
+  const int nks1 = p->Ka < p->K ? p->Ka >> KSH : nks;          // sub-steps of the first segment (Ka % (2 KSUB) == 0 if there are two)
   const int eW = *p->EW;                                      // the weight matrix's exponent (read once: a load inside the tile loop is awaited with
                                                               //  vmcnt(0), i.e. behind the next tile's operand requests)
   const int nst = (nks + 1) >> 1, nst1 = nks1 >> 1;          // stages; stages of the first segment (Ka % 32 == 0 if two)
@@ -68,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   // descriptor (its extent ends with row I - 1).
   auto a_lane_off = [&](int q, int ld, int l) -> unsigned {       // piece q of this wave: row, swizzled chunk
     const int row = 8 * (wave + 4 * q) + (l >> 3);
-    return (unsigned)row * (unsigned)ld * 4u + 16u * (unsigned)((l & 7) ^ ((row >> 1) & 7));
+    return (unsigned)row * (unsigned)ld * (unsigned)EB + 16u * (unsigned)((l & 7) ^ ((row >> 1) & 7));
   };
   // Lane-derived values that only a tile's prologue / epilogue needs are recomputed there from an opaque copy of the lane
   // index: derived from `lane` itself they are loop-invariant, get hoisted out of the tile loop and then occupy registers
@@ -108,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     i0 = ti * 128; j0 = tj * 256;
     const int lda = a->lda;
     const int i0a = (DIAG && (a->dbg & 8)) ? 0 : i0;
-    srdCur = make_srd(a->A + ((size_t)i0a * lda + a->a_col0) * 4, (DIAG && (a->dbg & 1)) ? 0u : clamp_bytes(((unsigned long long)(a->I - i0a - 1) * lda + a->Ka) * 4ull));
+    srdCur = make_srd(a->A + ((size_t)i0a * lda + a->a_col0) * EB, (DIAG && (a->dbg & 1)) ? 0u : clamp_bytes(((unsigned long long)(a->I - i0a - 1) * lda + a->Ka) * (unsigned long long)EB));
     sbias_st = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) voCur[q] = a_lane_off(q, lda, l);
@@ -119,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     auto exp_of = [&](int s) {
       const bool seg2 = s >= nks1;
       const int* E = seg2 ? EA2 : EA1;
-      const int col = seg2 ? ac2 + 16 * (s - nks1) : ac1 + 16 * s;
+      const int col = seg2 ? ac2 + KSUB * (s - nks1) : ac1 + KSUB * s;
       return E[(size_t)ti * (seg2 ? ncb2 : ncb1) + (col >> 7)];
     };
     eA = l < nks ? exp_of(l) : 0;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   auto enter_stage = [&](int S) {     // before the first piece of stage S
     if (__builtin_expect(S == seg_switch, 0)) {
       const kargs_t a = kargs();
-      srdCur = make_srd(a->A2 + ((size_t)i0 * a->lda2 + a->a2_col0) * 4, clamp_bytes(((unsigned long long)(a->I - i0 - 1) * a->lda2 + (a->K - a->Ka)) * 4ull));
+      srdCur = make_srd(a->A2 + ((size_t)i0 * a->lda2 + a->a2_col0) * EB, clamp_bytes(((unsigned long long)(a->I - i0 - 1) * a->lda2 + (a->K - a->Ka)) * (unsigned long long)EB));
       sbias_st = nst1;
 #pragma unroll
       for (int q = 0; q < 4; ++q) voCur[q] = a_lane_off(q, a->lda2, opaque(lane));
@@ -147,9 +155,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     const kargs_t a = kargs();
     if (sbias_st == 0) {
       const int i0a = (DIAG && (a->dbg & 8)) ? 0 : i0;
-      return make_srd_words(a->A + ((size_t)i0a * a->lda + a->a_col0) * 4, (DIAG && (a->dbg & 1)) ? 0u : clamp_bytes(((unsigned long long)(a->I - i0a - 1) * a->lda + a->Ka) * 4ull));
+      return make_srd_words(a->A + ((size_t)i0a * a->lda + a->a_col0) * EB, (DIAG && (a->dbg & 1)) ? 0u : clamp_bytes(((unsigned long long)(a->I - i0a - 1) * a->lda + a->Ka) * (unsigned long long)EB));
     }
-    return make_srd_words(a->A2 + ((size_t)i0 * a->lda2 + a->a2_col0) * 4, clamp_bytes(((unsigned long long)(a->I - i0 - 1) * a->lda2 + (a->K - a->Ka)) * 4ull));
+    return make_srd_words(a->A2 + ((size_t)i0 * a->lda2 + a->a2_col0) * EB, clamp_bytes(((unsigned long long)(a->I - i0 - 1) * a->lda2 + (a->K - a->Ka)) * (unsigned long long)EB));
   };
   const unsigned dst0_lds = (unsigned)__builtin_amdgcn_readfirstlane(lds_addr(dst0));
   auto headA = [&]() {
@@ -168,15 +176,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   // registers of the fragment set that is dead at the header as VALU temporaries, each with a WAW wait on a load.  A step
   // beyond K is rejected through the scalar offset.
   auto loadB2 = [&](int s, BFrag& b, int half) {     // two of the four weight loads of sub-step s
-    const unsigned so = s < nks ? ((w_ks0 + (unsigned)s) * w_rb32 + w_u0) * 2048u : OOB;
     // (s_nop 4: a scalar operand the compiler has just restored from a spill lane (v_readlane) needs five wait states before
     //  a vector-memory instruction reads it, and nothing inside an asm statement is padded for us)
-    if (half == 0)
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024"
-                   : "=&v"(b.h[0]), "=&v"(b.l[0]) : "v"(voW), "s"(srdW), "s"(so));
-    else
-      asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen offset:2048\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:3072"
-                   : "=&v"(b.h[1]), "=&v"(b.l[1]) : "v"(voW), "s"(srdW), "s"(so));
+    if constexpr (PL == 2) {     // unit (16-k step s, 32-row block) = 2 KiB [hi | lo]; half: the wave's first / second 32-row block
+      const unsigned so = s < nks ? ((w_ks0 + (unsigned)s) * w_rb32 + w_u0) * 2048u : OOB;
+      if (half == 0)
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024"
+                     : "=&v"(b.h[0]), "=&v"(b.l[0]) : "v"(voW), "s"(srdW), "s"(so));
+      else
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen offset:2048\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:3072"
+                     : "=&v"(b.h[1]), "=&v"(b.l[1]) : "v"(voW), "s"(srdW), "s"(so));
+    } else {                     // units of 1 KiB; half: the first / second 16-k step of the 32-deep sub-step (h / l registers), both 32-row blocks
+      const int s16 = 2 * s + half;
+      const unsigned so = s16 < nks16 ? ((w_ks0 + (unsigned)s16) * w_rb32 + w_u0) * 1024u : OOB;
+      if (half == 0)
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024"
+                     : "=&v"(b.h[0]), "=&v"(b.h[1]) : "v"(voW), "s"(srdW), "s"(so));
+      else
+        asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024"
+                     : "=&v"(b.l[0]), "=&v"(b.l[1]) : "v"(voW), "s"(srdW), "s"(so));
+    }
   };
   // everything but the six youngest requests (= the previous sub-step's) has landed; names the fragments so that no use of
   // them can be scheduled above the wait
@@ -253,27 +272,42 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       const f16x8 bl0 = __builtin_bit_cast(f16x8, bc.l[0]), bl1 = __builtin_bit_cast(f16x8, bc.l[1]);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
-        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, fa.h[mi], acc[mi][0], 0, 0, 0);
-        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, fa.h[mi], acc[mi][1], 0, 0, 0);
+        if constexpr (PL == 2) {
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, fa.h[mi], acc[mi][0], 0, 0, 0);
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, fa.h[mi], acc[mi][1], 0, 0, 0);
+        } else {   // one plane: fa.h / the h registers = the first 16 k of the sub-step, fa.l / the l registers = the second
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.h[mi], acc[mi][0], 0, 0, 0);
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.h[mi], acc[mi][1], 0, 0, 0);
+        }
         if (mi < 2) loadB2(s + 2, bn, mi);
         if (mi == 2 && u == 0) enter_stage((s >> 1) + 2);
         if (mi >= 2) issueA((s >> 1) + 2, (slot + 2) % KC_RING, 2 * u + (mi - 2));   // two of the four pieces of stage S + 2
-        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.l[mi], acc[mi][0], 0, 0, 0);
-        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.l[mi], acc[mi][1], 0, 0, 0);
+        if constexpr (PL == 2) {
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.l[mi], acc[mi][0], 0, 0, 0);
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.l[mi], acc[mi][1], 0, 0, 0);
+        }
         if (mi == 0 && u == 1) { __builtin_amdgcn_sched_barrier(0); barrier_raw(); __builtin_amdgcn_sched_barrier(0); }
-        const f16x8 nl = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
-        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.h[mi], acc[mi][0], 0, 0, 0);
-        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.h[mi], acc[mi][1], 0, 0, 0);
-        fa.l[mi] = nl;
-        fa.h[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);
+        if constexpr (PL == 2) {
+          const f16x8 nl = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.h[mi], acc[mi][0], 0, 0, 0);
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.h[mi], acc[mi][1], 0, 0, 0);
+          fa.l[mi] = nl;
+          fa.h[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);
+        } else {
+          const f16x8 nh = ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);   // fa.h[mi] has issued its last MFMA
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, fa.l[mi], acc[mi][0], 0, 0, 0);
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, fa.l[mi], acc[mi][1], 0, 0, 0);
+          fa.h[mi] = nh;
+          fa.l[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep the blocks apart: left alone, the scheduler gathers the reads at the end
       }
     };
     // Tile start: W(0), W(1) and this wave's pieces of stages 0 AND 1 are home (sub-steps 0 and 1 have no wait of their own,
     // and the barrier inside sub-step 1 publishes stage 1).  First tile: they are the only requests.  Later tiles: they were
-    // requested during the previous epilogue, which has issued at least 32 stores since.  The barrier also ends every wave's
+    // requested during the previous epilogue, which has issued at least 32 (one plane: 16) stores since.  The barrier also ends every wave's
     // use of the epilogue's LDS regions before the requests of stage 2 go out.
-    if (first) wait_vm<0>(); else wait_vm<32>();
+    if (first) wait_vm<0>(); else wait_vm<(PL == 2 ? 32 : 16)>();   // (one plane: 4 blocks x 4 stores per tile)
     pin_b(bq0); pin_b(bq1);
     barrier_raw();
     // The tile after this one: drawn from the counter of the workgroup's XCD group while this tile's k-loop runs (a returning
@@ -342,8 +376,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     const int nrows = min(128, e->I - c_i0);                      // > 0: the grid covers ceil(I / 128) row tiles
     const int jw = c_j0 + wj0;                                   // first column of the wave
     const bool wave_cols = jw < e->J;
-    const size_t offC = uniform_sz(((size_t)c_i0 * e->ldc + e->c_col0) * 4);
-    const srd_t srdC = make_srd(e->C + offC, (DIAG && (e->dbg & 4)) ? 0u : clamp_bytes(((unsigned long long)(nrows - 1) * e->ldc + e->J) * 4ull));
+    const size_t offC = uniform_sz(((size_t)c_i0 * e->ldc + e->c_col0) * EB);
+    const srd_t srdC = make_srd(e->C + offC, (DIAG && (e->dbg & 4)) ? 0u : clamp_bytes(((unsigned long long)(nrows - 1) * e->ldc + e->J) * (unsigned long long)EB));
     // Plane strip of one (32-point block, 32-column half) = [32 points][128 B]: the two 64-byte groups [hi | lo] of the
     // half as they lie in memory, chunk c at position c ^ (point & 7).  A el writes its 16-byte pieces (eight consecutive
     // lanes: eight positions = all 32 banks), then the wave reads the strip back eight whole rows per instruction and stores
@@ -352,15 +386,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     const unsigned sw_off = (unsigned)pt * 128u;
     const int srow = el >> 3, schunk = el & 7;
     const unsigned sr_off = (unsigned)srow * 128u + 16u * (unsigned)(schunk ^ srow);       // + 1024 per pass (8 rows: same swizzle)
-    unsigned voC[2];                                                                       // per 32-column half (J % 16 == 0)
+    // One plane: a strip row (128 B) holds all 64 columns of the wave for one point -- chunk 4 nj + 2 gg + lh = eight columns --
+    // and is flushed once per 32-point block instead of once per (block, 32-column half).
+    unsigned voC[2];                                                                       // per 32-column half (J % 16 == 0); one plane: [0] only
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj)
-      voC[nj] = jw + 32 * nj + 16 * (schunk >> 2) < e->J ? (unsigned)srow * (unsigned)e->ldc * 4u + (unsigned)((jw >> 4) + 2 * nj) * 64u + 16u * (unsigned)schunk : OOBH;
-    const unsigned stepC8 = 8u * (unsigned)e->ldc * 4u;
+      voC[nj] = PL == 2 ? (jw + 32 * nj + 16 * (schunk >> 2) < e->J ? (unsigned)srow * (unsigned)e->ldc * 4u + (unsigned)((jw >> 4) + 2 * nj) * 64u + 16u * (unsigned)schunk : OOBH)
+                        : (jw + 8 * schunk < e->J ? (unsigned)srow * (unsigned)e->ldc * 2u + (unsigned)jw * 2u + 16u * (unsigned)schunk : OOBH);
+    const unsigned stepC8 = 8u * (unsigned)e->ldc * (unsigned)EB;
     auto strip_put = [&](int gg, const u32x4& hi, const u32x4& lo) {
       *reinterpret_cast<u32x4*>(strip + sw_off + 16 * ((4 * gg + lh) ^ (pt & 7))) = hi;
       *reinterpret_cast<u32x4*>(strip + sw_off + 16 * ((4 * gg + 2 + lh) ^ (pt & 7))) = lo;
     };
+    auto strip_put1 = [&](int nj, int gg, const u32x4& hi) {
+      *reinterpret_cast<u32x4*>(strip + sw_off + 16 * ((4 * nj + 2 * gg + lh) ^ (pt & 7))) = hi;
+    };
+    auto keep_planes1 = [](const u32x4 (&hi)[4]) { asm volatile("" ::"v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3])); };
     // HAZARD (measured on gfx950, not modelled by hipcc): a ds_write_b128 can fetch its data registers AFTER a younger
     // ds_read_b128 of the same wave has returned into them.  The compiler, free to do so, gave the read-back of the strip the
     // registers of the planes it had just written; with the LDS busy (co-resident workgroup) single dwords of the written
@@ -391,6 +432,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         unsigned sw = 0u;
+        u32x4 ph1[4];
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
           u32x4 phi[2], plo[2];
@@ -401,11 +443,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = fmaf(acc[mi][nj][8 * gg + c], su, bj[gq][c]);
             sinpi8<SIGNS, SINM>(v, sw);
-            split8(v, 8192.f, phi[gg], plo[gg]);
-            strip_put(gg, phi[gg], plo[gg]);
+            if constexpr (PL == 2) {
+              split8(v, 8192.f, phi[gg], plo[gg]);
+              strip_put(gg, phi[gg], plo[gg]);
+            } else {
+              cvt8(v, 8192.f, ph1[gq]);
+              strip_put1(nj, gg, ph1[gq]);
+            }
           }
-          strip_flush(mi, nj);
-          keep_planes(phi, plo);
+          if constexpr (PL == 2) {
+            strip_flush(mi, nj);
+            keep_planes(phi, plo);
+          }
+        }
+        if constexpr (PL == 1) {
+          strip_flush(mi, 0);
+          keep_planes1(ph1);
         }
         if (SIGNS && e->Csign != nullptr && wave_cols && 32 * mi < nrows)
           e->Csign[((size_t)((c_i0 >> 5) + mi) * ((e->ldc + 63) >> 6) + ((e->c_col0 + jw) >> 6)) * 64 + el] = sw;
@@ -422,22 +475,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       // (swizzle on the source address): the lanes of a ds_read_b128 group hold 16 points that differ in q & 15 -> 16
       // different 16-byte slots of the 256-byte bank row.  The sign words (one dword per lane and block mi) come the same
       // way, all four ahead of the first half-block.
-      const size_t offH = uniform_sz(AUX != AUX_NONE ? ((size_t)c_i0 * e->ldh + e->h_col0) * 4 : 0);
+      // One plane: a half-block is 32 points x 64 B = 2 KiB in two pieces of 16 point rows; chunk c of row q at position
+      // c ^ ((q >> 2) & 3) (the 16 points of a ds_read_b128 group then cover the sixteen 16-byte slots of a 256-byte bank row).
+      const size_t offH = uniform_sz(AUX != AUX_NONE ? ((size_t)c_i0 * e->ldh + e->h_col0) * EB : 0);
       const srd_words srdH = make_srd_words(AUX != AUX_NONE ? e->H + offH : nullptr,
-                                            AUX != AUX_NONE ? clamp_bytes(((unsigned long long)(nrows - 1) * e->ldh + e->J) * 4ull) : 0u);
+                                            AUX != AUX_NONE ? clamp_bytes(((unsigned long long)(nrows - 1) * e->ldh + e->J) * (unsigned long long)EB) : 0u);
+      constexpr int HPC = PL == 2 ? 4 : 2;                        // 1 KiB pieces per half-block
       const unsigned hbuf[2] = {(unsigned)__builtin_amdgcn_readfirstlane(lds_addr(lds + 2 * KC_A + wave * 4096)),
                                 (unsigned)__builtin_amdgcn_readfirstlane(lds_addr(lds + KC_XREG + wave * 4096))};
-      const int hq = el >> 3;                                     // point row inside a piece
+      const int hq = PL == 2 ? el >> 3 : el >> 2;                 // point row inside a piece
       auto dma_h = [&](int hb) {
         if (AUX == AUX_NONE) return;
         const int nj = hb >> 2, mi = hb & 3;
 #pragma unroll
-        for (int pc = 0; pc < 4; ++pc) {
-          const int q = 8 * pc + hq;                              // point row inside the block
-          const int c = (el & 7) ^ ((q >> 1) & 7);                // chunk of the half-row this lane fetches
-          const bool ok = jw + 32 * nj + 16 * (c >> 2) < e->J;
-          const unsigned vo = ok ? (unsigned)q * (unsigned)e->ldh * 4u + (unsigned)((jw >> 4) + 2 * nj) * 64u + 16u * (unsigned)c : OOBH;
-          dma16_asm(srdH, hbuf[hb & 1] + (unsigned)(pc * 1024), vo, (unsigned)(32 * mi) * (unsigned)e->ldh * 4u);
+        for (int pc = 0; pc < HPC; ++pc) {
+          if constexpr (PL == 2) {
+            const int q = 8 * pc + hq;                              // point row inside the block
+            const int c = (el & 7) ^ ((q >> 1) & 7);                // chunk of the half-row this lane fetches
+            const bool ok = jw + 32 * nj + 16 * (c >> 2) < e->J;
+            const unsigned vo = ok ? (unsigned)q * (unsigned)e->ldh * 4u + (unsigned)((jw >> 4) + 2 * nj) * 64u + 16u * (unsigned)c : OOBH;
+            dma16_asm(srdH, hbuf[hb & 1] + (unsigned)(pc * 1024), vo, (unsigned)(32 * mi) * (unsigned)e->ldh * 4u);
+          } else {
+            const int q = 16 * pc + hq;
+            const int c = (el & 3) ^ ((q >> 2) & 3);                // eight columns each
+            const bool ok = jw + 32 * nj + 8 * c < e->J;
+            const unsigned vo = ok ? (unsigned)q * (unsigned)e->ldh * 2u + (unsigned)(jw + 32 * nj) * 2u + 16u * (unsigned)c : OOBH;
+            dma16_asm(srdH, hbuf[hb & 1] + (unsigned)(pc * 1024), vo, (unsigned)(32 * mi) * (unsigned)e->ldh * 2u);
+          }
         }
       };
       if (AUX == AUX_SINREC) {
@@ -470,16 +534,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
           if (AUX != AUX_NONE) {
             // half-block hb (and everything older: the sign words) is home when all but the four pieces of hb + 1 are
             // ... and, for half-blocks 0 and 1, the 8 pieces of the next tile's first two A stages requested behind them
-            if (hb == 7) wait_vm<0>(); else if (hb < 2 && more) wait_vm<12>(); else wait_vm<4>();
+            if (hb == 7) wait_vm<0>(); else if (hb < 2 && more) wait_vm<HPC + 8>(); else wait_vm<HPC>();
             const char* hreg = (hb & 1) ? lds + KC_XREG + wave * 4096 : lds + 2 * KC_A + wave * 4096;
             if (AUX == AUX_SINREC && nj == 0) sword[mi] = *reinterpret_cast<const unsigned*>(lds + KC_HSIGN + wave * 1024 + mi * 256 + el * 4) ^ sflip;
 #pragma unroll
             for (int gg = 0; gg < 2; ++gg) {
-              hh[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 128 + 16 * ((4 * gg + lh) ^ ((pt >> 1) & 7)));
-              hl[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 128 + 16 * ((4 * gg + 2 + lh) ^ ((pt >> 1) & 7)));
+              if constexpr (PL == 2) {
+                hh[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 128 + 16 * ((4 * gg + lh) ^ ((pt >> 1) & 7)));
+                hl[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 128 + 16 * ((4 * gg + 2 + lh) ^ ((pt >> 1) & 7)));
+              } else {
+                hh[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 64 + 16 * ((2 * gg + lh) ^ ((pt >> 2) & 3)));
+              }
             }
             if (hb + 2 < 8) {   // the buffer is free once these reads have returned
-              asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hl[0]), "+v"(hl[1]), "+v"(sword[mi])::"memory");
+              if constexpr (PL == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hl[0]), "+v"(hl[1]), "+v"(sword[mi])::"memory");
+              else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(sword[mi])::"memory");
               dma_h(hb + 2);
             }
           }
@@ -498,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
             }
             if (AUX != AUX_NONE) {
               float h[8];
-              join8(hh[gg], hl[gg], inv_h, h);
+              if constexpr (PL == 2) join8(hh[gg], hl[gg], inv_h, h); else join8_1(hh[gg], inv_h, h);
               if (AUX == AUX_SINREC) {
                 // w0 cos(w0 z) = +-|w0| sqrt(1 - h^2): the sign bit (xor-ed with w0's own sign, once per word) is shifted to
                 // bit 31 and merged over |w0| 2^-e by one v_bfi; 1 - h^2 is clamped at 0 by the FMA's output modifier
@@ -549,7 +618,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       if (more) headW();     // the registers of pass A are free: the next tile's first weight fragments go out ahead of the stores
       // ---- pass B: split, through the strip, store
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < 4; ++mi) {
+        u32x4 ph1[4];
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
           u32x4 phi[2], plo[2];
@@ -558,12 +628,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
             float v[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) v[c] = acc[mi][nj][8 * gg + c];
-            split8(v, sc, phi[gg], plo[gg]);
-            strip_put(gg, phi[gg], plo[gg]);
+            if constexpr (PL == 2) {
+              split8(v, sc, phi[gg], plo[gg]);
+              strip_put(gg, phi[gg], plo[gg]);
+            } else {
+              cvt8(v, sc, ph1[2 * nj + gg]);
+              strip_put1(nj, gg, ph1[2 * nj + gg]);
+            }
           }
-          strip_flush(mi, nj);
-          keep_planes(phi, plo);
+          if constexpr (PL == 2) {
+            strip_flush(mi, nj);
+            keep_planes(phi, plo);
+          }
         }
+        if constexpr (PL == 1) {
+          strip_flush(mi, 0);
+          keep_planes1(ph1);
+        }
+      }
     }
     if (!more) break;
     vb = vbn;
@@ -618,7 +700,8 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   const dim3 grid(ntiles < slots ? ntiles : slots), block(256);   // persistent workgroups, two per CU; tile = block + n * grid
   const int tok = prof_hook_begin(2.0 * a.I * (double)a.J * a.K, 0, st);
   const bool cs = a.colsum != nullptr;
-#define KC_LAUNCH(ACT_, AUX_, CS_, SG_, SM_) hipLaunchKernelGGL((gemm_kc_kernel<ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a)
+#define KC_LAUNCH(ACT_, AUX_, CS_, SG_, SM_) do { if (a.pl == 2) hipLaunchKernelGGL((gemm_kc_kernel<2, ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a); \
+                                                 else hipLaunchKernelGGL((gemm_kc_kernel<1, ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a); } while (0)
   if (a.aux_mode == AUX_SINREC) KC_LAUNCH(ACT_NONE, AUX_SINREC, true, false, SIN_POLY);
   else if (a.aux_mode == AUX_RELU_MASK) KC_LAUNCH(ACT_NONE, AUX_RELU_MASK, true, false, SIN_POLY);
   else if (a.act == ACT_SIN) {

@@ -1,8 +1,7 @@
-// Forward / backward launch sequences of one rendering pass in the default arithmetic: every activation tensor lives
-// as block-scaled fp16 planes (bsp.h), every dense layer is one launch of bsp_gemm.hip, weights come pre-packed in
-// fragment order.  Same math, same order of layers and the same workspace roles as the fp32-storage sequences in
-// api.hip (which serve the other arithmetic modes); reference: semantic/models/rs_semantic.py:260-340 (forward),
-// its autograd backward.
+// Forward / backward launch sequences of one rendering pass: every activation tensor lives as block-scaled fp16 planes
+// (bsp.h; two planes in the default arithmetic, one under SNERF_FLAG_F16X1 -- Plan::pl, the kernels are templated on it),
+// every dense layer is one launch of bsp_kc.hip / bsp_gemm.hip, weights come pre-packed in fragment order.
+// Reference: semantic/models/rs_semantic.py:260-340 (forward), its autograd backward.
 #include "aux_kernels.h"
 #include "bsp.h"
 #include "composite.h"
@@ -28,8 +27,9 @@ void weights(bsp::KcArgs& g, const Plan& p, const float* pk, int job, int row0 =
   g.W = planes + p.wj_off[job];
   g.EW = reinterpret_cast<const int*>(planes + p.wp_bytes) + p.wj_e[job];
   g.w_rb32 = (p.wj_rows[job] + 31) / 32;
-  g.w_bytes = (unsigned)bsp::wp16_bytes(p.wj_rows[job], p.wj_K[job]);
+  g.w_bytes = (unsigned)bsp::wp16_bytes(p.wj_rows[job], p.wj_K[job], p.pl);
   g.w_row0 = row0; g.w_k0 = k0;
+  g.pl = p.pl;
 }
 }  // namespace
 
@@ -54,9 +54,10 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
   ea.dir_is_sun = (p.sc && !in->xyz) ? 1 : 0;
   ea.N = p.N; ea.S = p.S; ea.F = p.F; ea.Ep = p.Ep;
   ea.FA = p.FA; ea.W = p.Wf; ea.Xp = p.Xp; ea.x_sun = p.x_sun; ea.x_t = p.x_t; ea.x_ts = p.x_ts; ea.tau = p.tau;
-  RC(bsp::launch_encode_bsp(ea, ws.c(p.o_pe), ws.i(p.e_pe), ws.c(p.o_fa), ws.i(p.e_fa), p.Wf, st));
+  RC(bsp::launch_encode_bsp(ea, ws.c(p.o_pe), ws.i(p.e_pe), ws.c(p.o_fa), ws.i(p.e_fa), p.Wf, p.pl, st));
+  const size_t EB = 2 * (size_t)p.pl;   // bytes per element of a plane tensor
   if (p.Wf > W)   // pad columns between feats and extras (narrow test networks only): zero planes, read against zero weights
-    RC(bsp::launch_zero_cols(ws.c(p.o_fa) + (size_t)W * 4, (size_t)p.FA * 4, (size_t)(p.Wf - W) * 4, P, st));
+    RC(bsp::launch_zero_cols(ws.c(p.o_fa) + (size_t)W * EB, (size_t)p.FA * EB, (size_t)(p.Wf - W) * EB, P, st));
   // 3. trunk (rs_semantic.py:325-334)
   const int act = p.siren ? ACT_SIN : ACT_RELU;
   for (int i = 0; i < p.L; ++i) {
@@ -163,7 +164,7 @@ int dw_gemm(const Plan& p, const DwMat& m, const char* dz, const int* edz, int l
   g.B = X; g.EB = ex; g.ldb = ldx; g.b_col0 = x_col0;
   g.I = I; g.J = J; g.P = p.P;
   g.C = m.slab + slab_off; g.ldc = m.ldw;
-  g.k_split = m.sp.k_split; g.n_split = m.sp.ns; g.slab_stride = m.stride;
+  g.k_split = m.sp.k_split; g.n_split = m.sp.ns; g.slab_stride = m.stride; g.pl = p.pl;
   return bsp::launch_dw(g, narrow_i, st);
 }
 int dw_reduce(RQ& rq, const DwMat& m, size_t count, float* gout) { return red_add_elem(rq.elem, m.slab, m.sp.ns, m.stride, count, gout); }
@@ -177,7 +178,7 @@ int bias_from_colsum(const Plan& p, RQ& rq, const float* cs, int width, float* g
 int narrow_grad(const Plan& p, RQ& rq, const float* dnar, char* planes, int* E, float* gout, hipStream_t st) {
   const int nb = (p.P + 255) / 256;
   float* part = rq.take((size_t)nb * NARROW);
-  RC(bsp::launch_colsum32_bsp(dnar, p.P, part, planes, E, st));
+  RC(bsp::launch_colsum32_bsp(dnar, p.P, part, planes, E, p.pl, st));
   return red_add_col(rq.col, part, nb, NARROW, NARROW, gout);
 }
 }  // namespace
@@ -289,8 +290,8 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     cs_ = colsum(g, p.FA);   // columns [0, W) = bias gradient of feats_from_xyz
     RC(launch_kc(g));
     RC(red_add_col(rq.col, cs_, (P + 127) / 128, (size_t)cs_ld(p.FA), W, gp + p.b_fs));
-    if (d_t) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_t, p.N, p.S, p.tau, d_t, st));
-    if (d_t_s && p.x_ts >= 0) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_ts, p.N, p.S, p.tau, d_t_s, st));
+    if (d_t) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_t, p.N, p.S, p.tau, d_t, p.pl, st));
+    if (d_t_s && p.x_ts >= 0) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_ts, p.N, p.S, p.tau, d_t_s, p.pl, st));
   }
   char* dz = ws.c(p.o_dza); int* edz = ws.i(p.e_dza);   // dz1 is dead from here on
   {  // 4. feats + sigma: dW for the [W + 32][W] matrix, then dz of the last trunk layer

@@ -22,10 +22,10 @@ struct Plan {
   // first head layers fused into one GEMM: blocks of H rows; sun block last
   int nblk = 0, blk_rgb = 0, blk_sem = -1, blk_beta = -1, blk_sbeta = -1, blk_sun = -1;
   int N1 = 0;   // rows of the fused first-head-layer matrix = KF + H
-  int KF = 0;   // contraction length of the block-diagonal final-layer matrix: all blocks but sun, (nblk - 1) H -- in the
-                // block-scaled plane layout (fmt 1) rounded up to 128 so that the sun block starts on an exponent block
+  int KF = 0;   // contraction length of the block-diagonal final-layer matrix: all blocks but sun, (nblk - 1) H, rounded up to
+                // 128 so that the sun block starts on an exponent block
   int sun_col = 0;  // first row of the sun block in the fused first-layer matrix / its column in the h1 buffer (= KF)
-  int Wf = 0;   // column of the extras block [sun | t | t_s] behind the feats columns: W (fmt 1: rounded up to 128)
+  int Wf = 0;   // column of the extras block [sun | t | t_s] behind the feats columns: W rounded up to 128
   bool rgb_t = false, sem_t = false, sem_ts = false, sbeta_ts = false;
   // final-layer output columns inside the NARROW-wide buffer
   static constexpr int col_rgb = 0, col_beta = 3, col_sbeta = 4, col_sem = 5;
@@ -40,19 +40,10 @@ struct Plan {
   size_t w_fin = 0, b_fin = 0;      // [NARROW][KF]
   size_t sky = 0;                   // [H][4] w0 | [H] b0 | [4][H] w2 | [4] b2
   int sky_floats = 0;
-  // K-contiguous transposes for the dX GEMMs (dX = dZ . W reads W^T rows): [cols of W][rows of W]
-  size_t t_tr[SNERF_MAX_LAYERS] = {0};  // h part of trunk layer i: [W][W]
-  size_t t_fs = 0;   // [W][W + NARROW]
-  size_t t_h1 = 0;   // [FA][N1]
-  size_t t_s2 = 0, t_s3 = 0;  // [H][H]
-  size_t t_s4 = 0;   // [H][NARROW]
-  size_t t_fin = 0;  // [KF][NARROW]
-  size_t n_fp32 = 0;         // floats of the fp32 region (parameters + transposes); bf16 planes follow it
-  size_t packed_floats = 0;  // whole packed buffer in floats: fp32 region + 3 bf16 planes of it
-  int fmt = 0;       // 1: block-scaled fp16 planes (csrc/bsp.h; no arithmetic flag = the default); 0: fp32 activations (split3 / fp32 / bf16 modes)
-  bool sign_deriv = true;  // SIREN derivative kept as sign bits + recomputed from h (false: stored w0*cos floats)
-  int planes = 3;    // planes per operand: fmt 1: 2 fp16 (default); fmt 0: 3 bf16 (SNERF_FLAG_SPLIT3), 2 (SNERF_FLAG_BF16X3), 1 (SNERF_FLAG_BF16)
-  bool x6 = true;    // split-bf16 MFMA for the 128x128 GEMMs (fp32 MFMA when SNERF_FLAG_FP32_MFMA)
+  size_t n_fp32 = 0;         // floats of the fp32 region (the parameters; gradients use the same layout); the weight packs follow it
+  size_t packed_floats = 0;  // whole packed buffer in floats: fp32 region + WF16 packs + exponents
+  int pl = 2;        // fp16 planes of every activation tensor and weight pack (csrc/bsp.h): 2 = the default arithmetic (SNERF_FLAG_F16X2),
+                     // 1 = SNERF_FLAG_F16X1 (reduced precision)
 
   // workspace layout (byte offsets)
   size_t o_z = 0, o_T = 0, o_rgbraw = 0, o_pe = 0, o_fa = 0, o_h1 = 0, o_c1 = 0;
@@ -61,11 +52,11 @@ struct Plan {
   size_t o_sigo = 0, o_fino = 0, o_suno = 0;
   // backward scratch
   size_t o_dza = 0, o_dzb = 0, o_dsa = 0, o_dsb = 0, o_dsig = 0, o_dfin = 0, o_dsun = 0;
-  size_t o_colsum = 0, o_colsum2 = 0, o_slab = 0, o_slab2 = 0, o_skyslab = 0;
+  size_t o_skyslab = 0;
   size_t o_kcq = 0;                 // tile counters of the K-contiguous launches: KCQ_SLOTS slots of 64 bytes, zeroed at the start of a pass
   size_t o_rq = 0, rq_floats = 0;   // reduction arena of the block-scaled plane backward (bsp_pass.hip: per-launch slabs / column-sum partials)
-  // ---- block-scaled plane layout (fmt 1; csrc/bsp.h): every activation buffer above holds G16 planes instead of fp32
-  //      (same bytes) and has an exponent table; the 32-wide head gradients also exist as planes
+  // ---- block-scaled plane layout (csrc/bsp.h): every activation buffer above holds G16 planes and has an exponent table; the
+  //      32-wide head gradients also exist as planes
   size_t e_pe = 0, e_fa = 0, e_h1 = 0, e_s2 = 0, e_s3 = 0, e_h[SNERF_MAX_LAYERS] = {0};
   size_t e_dza = 0, e_dzb = 0, e_dsa = 0, e_dsb = 0, e_dsig = 0, e_dfin = 0, e_dsun = 0;
   size_t o_pdsig = 0, o_pdfin = 0, o_pdsun = 0;          // planes [Pp][32] of the narrow gradients
@@ -82,13 +73,11 @@ struct Plan {
   int maxw = 0;      // widest dz buffer
   int nrb = 0;       // 32-row blocks (colsum partials)
   int comp_blocks = 0;
-  size_t slab_floats = 0;
   size_t ws_bytes = 0;
 };
 
 constexpr int KCQ_SLOTS = 64;
 struct DwSplit { int ns = 1; int k_split = 32; };
-DwSplit dw_choose(int P, int rows, int cols, bool narrow_rows);
 DwSplit dw_choose_bsp(int P, int rows, int cols, bool narrow_rows);
 
 // returns SNERF_OK or an error (message via set_error)

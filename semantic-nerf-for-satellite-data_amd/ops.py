@@ -17,8 +17,8 @@ _WS_POISON = os.environ.get("SNERF_WS_POISON", "0") == "1"
 
 from . import _lib
 
-# SNERF_MFMA=f16x2|split3|fp32|split3_bwd2|split2|bf16 overrides every ModelSpec.mfma (diagnostics, bench.py --mfma);
-# unset, ModelSpec.mfma decides and its default is f16x2 -- the arithmetic a C caller gets with no arithmetic flag
+# SNERF_MFMA=f16x2|f16x1 overrides every ModelSpec.mfma (diagnostics); unset, ModelSpec.mfma decides and its default is f16x2 --
+# the arithmetic a C caller gets with no arithmetic flag
 BASE_FLAGS = _lib.MFMA_FLAGS.get(os.environ.get("SNERF_MFMA", "").lower())
 
 
@@ -27,20 +27,22 @@ DEFAULT_MFMA = "f16x2"
 
 def mfma_mode(pipeline_cfg=None, run_cfg=None) -> str:
     """Matrix-unit arithmetic of the dense layers from the reference's two precision knobs:
-    `precision` (baseline/pipelines/nerf.py:65; 16 = half precision) and the run config's
-    `float32_matmul_precision` (framework/configs.py:26, applied at framework/pipelines.py:254-256).  The build adds
-    the pipeline field `mfma_precision`: "f16x2" (default: two fp16 planes of power-of-two-scaled operands, three
-    products, fp32-class results at half the matrix work of split3), "split3" (three bf16 planes per fp32 operand, six
-    products: fp32-class with per-element 24-bit operands), "fp32" (v_mfma_f32_32x32x2_f32), "split3_bwd2" / "split2"
-    (two bf16 planes, ~16 significant bits: what torch calls "high"; backward only / everywhere), "bf16" (one plane:
-    "medium" / precision = 16), or "auto" = follow float32_matmul_precision (highest / high / medium)."""
+    `precision` (baseline/pipelines/nerf.py:65, handed to the trainer at framework/pipelines.py:319; 16 = half precision) and the
+    run config's `float32_matmul_precision` (framework/configs.py:26, applied at framework/pipelines.py:254-256).  The build adds
+    the pipeline field `mfma_precision`:
+      "f16x2" (default)  two fp16 planes of block-scaled operands (22 significant bits), three products: fp32-class results
+      "f16x1" / "bf16"   REDUCED precision: ONE fp16 plane of the same block-scaled tensors (11 significant bits -- the operand
+                         precision of TF32, three bits more than bf16), one product, half the activation bytes.  `precision = 16`
+                         selects it; "bf16" is the name BASELINE.json's configs[2] / [4] use and maps to the same mode
+      "auto"             follow float32_matmul_precision: "highest" -> f16x2; "high" (TF32-class on the reference's hardware) and
+                         "medium" -> f16x1"""
     mode = getattr(pipeline_cfg, "mfma_precision", DEFAULT_MFMA)
     if getattr(pipeline_cfg, "precision", 32) == 16:
-        return "bf16"
+        return "f16x1"
     if mode == "auto":
-        return {"highest": "split3", "high": "split2", "medium": "bf16"}[
+        return {"highest": "f16x2", "high": "f16x1", "medium": "f16x1"}[
             getattr(run_cfg, "float32_matmul_precision", "highest")]
-    return mode
+    return "f16x1" if mode == "bf16" else mode
 
 # parameter names in the reference's state_dict order (SURVEY.md 8(b)) -> SnerfParams field
 _HEAD_FIELDS = {
@@ -619,13 +621,3 @@ def sample_z(rays: torch.Tensor, z_steps: torch.Tensor, u: torch.Tensor | None) 
     with torch.cuda.device(rays.device):
         _lib.check(L.snerf_sample_z(_ptr(rays), _ptr(z_steps.contiguous()), _ptr(uc), _ptr(z), N, S, _stream()), "snerf_sample_z")
     return z
-
-
-def test_gemm(A: torch.Tensor, B: torch.Tensor, a_ic: bool, b_ic: bool, I: int, J: int, K: int, narrow: int = 0):
-    """C[I,J] = sum_k A(i,k) B(j,k) through the library's tiled MFMA kernel (test hook)."""
-    L = _lib.lib()
-    Cm = torch.full((I, J), float("nan"), dtype=torch.float32, device=A.device)
-    with torch.cuda.device(A.device):
-        _lib.check(L.snerf_test_gemm(_ptr(A), A.stride(0), int(a_ic), _ptr(B), B.stride(0), int(b_ic), _ptr(Cm), J,
-                                     I, J, K, narrow, _stream()), "snerf_test_gemm")
-    return Cm

@@ -10,7 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "legacy_arithmetic: exercises the round-1 kernels of csrc/legacy/ (arithmetic flags SPLIT3 / FP32_MFMA / BF16*), not the default path")
 
 
 @pytest.fixture(scope="session")

@@ -42,8 +42,13 @@ def test_host_only_sizes_and_errors():
     spec = ModelSpec()
     d = spec.desc(4096, 64, _lib.FLAG_TRAIN)
     n = L.snerf_packed_floats(C.byref(d))
-    # 2,826,766 parameters + padding of the packed layout + K-contiguous transposes for the dX GEMMs
-    assert 2 * 2_500_000 < n < 15_000_000  # + three bf16 planes of the fp32 region
+    # 2,826,766 parameters + padding of the packed layout, then one two-plane WF16 pack per weight operand (every
+    # matrix and its transpose for dX: 4 bytes per element each)
+    assert 3 * 2_800_000 < n < 15_000_000
+    d1 = spec.desc(4096, 64, _lib.FLAG_TRAIN | _lib.FLAG_F16X1)
+    n1 = L.snerf_packed_floats(C.byref(d1))
+    assert 2 * 2_800_000 < n1 < n                                          # one-plane packs: half the bytes behind the fp32 region
+    assert L.snerf_grad_floats(C.byref(d1)) == L.snerf_grad_floats(C.byref(d))
     train = L.snerf_workspace_bytes(C.byref(d))
     d.flags = 0
     infer = L.snerf_workspace_bytes(C.byref(d))
@@ -54,18 +59,18 @@ def test_host_only_sizes_and_errors():
     bad = ModelSpec(fc_units=520).desc(16, 8)
     assert L.snerf_packed_floats(C.byref(bad)) == 0
     assert b"fc_units" in L.snerf_last_error()
-    # arithmetic flags are exclusive (flags = 0 is the default arithmetic, f16x2); split3_bwd2 may name its forward mode
-    sel = (_lib.FLAG_F16X2, _lib.FLAG_SPLIT3, _lib.FLAG_FP32_MFMA, _lib.FLAG_BF16, _lib.FLAG_BF16X3, _lib.FLAG_BWD_BF16X3)
-    for a in sel:
-        for b in sel:
-            d = ModelSpec().desc(16, 8, a | b)
-            ok = a == b or {a, b} == {_lib.FLAG_SPLIT3, _lib.FLAG_BWD_BF16X3}
-            assert (L.snerf_workspace_bytes(C.byref(d)) != 0) == ok, (a, b)
-            if not ok:
-                assert b"arithmetic flag" in L.snerf_last_error()
+    # the two arithmetic flags exclude each other (flags = 0 is the default arithmetic, f16x2)
+    both = ModelSpec().desc(16, 8, _lib.FLAG_F16X2 | _lib.FLAG_F16X1)
+    assert L.snerf_workspace_bytes(C.byref(both)) == 0 and b"arithmetic flag" in L.snerf_last_error()
+    one = ModelSpec(fc_units=64, feat_last=32).desc(64, 8, _lib.FLAG_TRAIN | _lib.FLAG_F16X1)
+    two = ModelSpec(fc_units=64, feat_last=32).desc(64, 8, _lib.FLAG_TRAIN)
+    assert 0 < L.snerf_workspace_bytes(C.byref(one)) < L.snerf_workspace_bytes(C.byref(two))   # 2 bytes per stored activation element
+    odd = ModelSpec(fc_units=96, feat_last=48).desc(16, 8, _lib.FLAG_F16X1)                       # one plane: LDS stages of 64 columns
+    assert L.snerf_workspace_bytes(C.byref(odd)) == 0 and b"fc_units % 64" in L.snerf_last_error()
+    assert L.snerf_workspace_bytes(C.byref(ModelSpec(fc_units=96, feat_last=48).desc(16, 8))) > 0
     # the default arithmetic is the same object for a C caller (flags = 0) and for Python's ModelSpec()
     assert L.snerf_workspace_bytes(C.byref(ModelSpec().desc(64, 8))) == L.snerf_workspace_bytes(C.byref(ModelSpec().desc(64, 8, _lib.FLAG_F16X2)))
-    assert L.snerf_version() == 2
+    assert L.snerf_version() == 3
 
 
 def test_plan_builder_over_model_variants_and_null_arguments():
@@ -82,7 +87,7 @@ def test_plan_builder_over_model_variants_and_null_arguments():
             spec = ModelSpec(**kw)
         except TypeError:
             continue
-        for flags in (0, _lib.FLAG_TRAIN, _lib.FLAG_SC_PASS, _lib.FLAG_TRAIN | _lib.FLAG_SC_PASS, _lib.FLAG_TRAIN | _lib.FLAG_SPLIT3, _lib.FLAG_BF16):
+        for flags in (0, _lib.FLAG_TRAIN, _lib.FLAG_SC_PASS, _lib.FLAG_TRAIN | _lib.FLAG_SC_PASS, _lib.FLAG_TRAIN | _lib.FLAG_F16X1, _lib.FLAG_F16X1, _lib.FLAG_F16X1 | _lib.FLAG_TRAIN | _lib.FLAG_SC_PASS):
             for N, S in ((1, 1), (77, 7), (4096, 64), (2048, 130)):
                 d = spec.desc(N, S, flags)
                 n, g, w = L.snerf_packed_floats(C.byref(d)), L.snerf_grad_floats(C.byref(d)), L.snerf_workspace_bytes(C.byref(d))

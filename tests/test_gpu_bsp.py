@@ -46,7 +46,7 @@ def test_planes_round_trip_and_block_exponents():
     ld, col0 = 384, 128
     y = torch.empty_like(x)
     E = torch.zeros(3 * 3, dtype=torch.int32, device=DEV)
-    lib.check(L.snerf_test_bsp_roundtrip(_p(x), rows, cols, ld, col0, _p(y), _p(E), _st()), "roundtrip")
+    lib.check(L.snerf_test_bsp_roundtrip(_p(x), rows, cols, ld, col0, _p(y), _p(E), 2, _st()), "roundtrip")
     # 22 significant bits relative to each BLOCK's maximum
     for rb in range(3):
         for cb in range(2):
@@ -55,6 +55,15 @@ def test_planes_round_trip_and_block_exponents():
             assert float((y[blk] - x[blk]).abs().max()) <= m * 2.0 ** -21, (rb, cb)
             e = int(E[rb * 3 + 1 + cb])
             assert 2.0 ** 13 <= m * 2.0 ** e < 2.0 ** 14, (rb, cb, e, m)
+    # ONE plane (SNERF_FLAG_F16X1): the same exponents, 11 significant bits relative to each block's maximum
+    y1 = torch.empty_like(x)
+    E1 = torch.zeros_like(E)
+    lib.check(L.snerf_test_bsp_roundtrip(_p(x), rows, cols, ld, col0, _p(y1), _p(E1), 1, _st()), "roundtrip, one plane")
+    assert torch.equal(E1, E)
+    for rb in range(3):
+        for cb in range(2):
+            blk = (slice(128 * rb, min(rows, 128 * rb + 128)), slice(128 * cb, min(cols, 128 * cb + 128)))
+            assert float((y1[blk] - x[blk]).abs().max()) <= float(x[blk].abs().max()) * 2.0 ** -10, (rb, cb)
 
 
 @pytest.fixture(params=[0, 3, 2], ids=["grid_default", "grid_3_workgroups", "grid_2_workgroups"])
@@ -69,7 +78,7 @@ def kc_grid(request):
 
 
 def _kc(A, W, bias=None, A2=None, act=ACT_NONE, w0=1.0, aux=AUX_NONE, Hact=None, Hsign=None, a_col0=0, c_col0=0,
-        want_sign=False, want_colsum=False, narrow=False):
+        want_sign=False, want_colsum=False, narrow=False, planes=2):
     L, lib = _lib()
     I, Ka = A.shape
     K = Ka + (A2.shape[1] if A2 is not None else 0)
@@ -79,7 +88,7 @@ def _kc(A, W, bias=None, A2=None, act=ACT_NONE, w0=1.0, aux=AUX_NONE, Hact=None,
     sign = torch.zeros(((I + 127) // 128 * 128 // 32) * ((ldc + 63) // 64) * 64, dtype=torch.int32, device=DEV) if want_sign else None
     cs = torch.zeros(((I + 127) // 128, J), device=DEV) if want_colsum else None
     lib.check(L.snerf_test_bsp_kc(_p(A), _p(A2), Ka, _p(W), _p(bias), I, J, K, a_col0, c_col0, act, w0, aux, _p(Hact), _p(Hsign),
-                                  _p(Cm), _p(sign), _p(cs), int(narrow), _st()), "test_bsp_kc")
+                                  _p(Cm), _p(sign), _p(cs), int(narrow), planes, _st()), "test_bsp_kc")
     return Cm, sign, cs
 
 
@@ -190,11 +199,11 @@ def test_kc_narrow_fp32_output(I, K):
     assert float(rows.max()) <= 3e-6, float(rows.max())
 
 
-def _dw(A, B, I, J, a_col0=0, b_col0=0, k_split=1024, narrow=False):
+def _dw(A, B, I, J, a_col0=0, b_col0=0, k_split=1024, narrow=False, planes=2):
     L, lib = _lib()
     P = A.shape[0]
     Cm = torch.full((I, J), float("nan"), device=DEV)
-    lib.check(L.snerf_test_bsp_dw(_p(A), A.shape[1], _p(B), B.shape[1], P, I, J, a_col0, b_col0, k_split, int(narrow), _p(Cm), _st()),
+    lib.check(L.snerf_test_bsp_dw(_p(A), A.shape[1], _p(B), B.shape[1], P, I, J, a_col0, b_col0, k_split, int(narrow), _p(Cm), planes, _st()),
               "test_bsp_dw")
     return Cm
 
@@ -269,3 +278,141 @@ def test_vanishing_blocks_next_to_loud_ones_stay_finite():
     refd = Zs.double().T @ Xs.double()
     assert bool(torch.isfinite(Cd).all())
     assert _relerr(Cd, refd) <= max(2.0 * _relerr(Zs.T @ Xs, refd), 3e-7)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ONE-PLANE form (SNERF_FLAG_F16X1, the reduced-precision mode): the same kernels instantiated for one fp16 plane.  Yardstick:
+# the error of the same contraction with both operands rounded to fp16 once (what one plane can hold at best); the block
+# exponents must keep that relative precision for quiet blocks next to loud ones (where a plain .half() would flush).
+# UNPINNED bars -- the reference runs no half-precision path here.
+# ---------------------------------------------------------------------------------------------------------------------
+def _err16(A, W, ref):
+    return _relerr(A.half().double() @ W.half().double().T, ref)
+
+
+@pytest.mark.parametrize("I,J,K", [(128, 256, 16), (300, 512, 512), (1000, 544, 528), (257, 48, 64), (4096, 1024, 544), (300, 256, 32)])
+def test_one_plane_kc_plain_bias_colsum(I, J, K, kc_grid):
+    g = torch.Generator().manual_seed(I + J + K)
+    A = torch.randn(I, K, generator=g).to(DEV)
+    W = (torch.randn(J, K, generator=g) * 0.05).to(DEV)
+    b = torch.randn(J, generator=g).to(DEV)
+    Cm, _, _ = _kc(A, W, b, planes=1)
+    ref = A.double() @ W.double().T + b.double()
+    assert _relerr(Cm, ref) <= 2.0 * _err16(A, W, A.double() @ W.double().T) + 1e-6 + 2.0 ** -11   # (+ the output's own rounding to one plane)
+    Cm0, _, cs = _kc(A, W, None, want_colsum=True, planes=1)
+    ref0 = A.double() @ W.double().T
+    assert _relerr(Cm0, ref0) <= 2.0 * _err16(A, W, ref0) + 2.0 ** -11
+    want = torch.stack([ref0[r:r + 128].sum(0) for r in range(0, I, 128)])
+    assert _relerr(cs, want) <= 2e-3            # column sums are taken from the fp32 values before they are rounded to the plane
+
+
+def test_one_plane_kc_two_segments_offsets_and_exponent_changes(kc_grid):
+    g = torch.Generator().manual_seed(7)
+    I, Ka, Kb, J = 384, 256, 288, 512
+    A = torch.randn(I, Ka, generator=g)
+    A[:, 128:] *= 2.0 ** -20
+    A[128:256] *= 2.0 ** 9
+    A2 = torch.randn(I, Kb, generator=g) * 37.0
+    W = torch.randn(J, Ka + Kb, generator=g)
+    A, A2, W = A.to(DEV), A2.to(DEV), W.to(DEV)
+
+    def check(Am, A2m, Wm, **kw):
+        Cm, _, _ = _kc(Am, Wm, None, A2=A2m, planes=1, **kw)
+        cat = Am if A2m is None else torch.cat([Am, A2m], 1)
+        ref = cat.double() @ Wm.double().T
+        rows = (Cm.double() - ref).norm(dim=1) / ref.norm(dim=1)
+        assert float(rows.max()) <= 2e-3, float(rows.max())
+    check(A, A2, W, a_col0=128, c_col0=256)
+    check(A, None, W[:, :Ka].contiguous(), a_col0=128)
+    Wz = W.clone()
+    Wz[:, :128] = 0
+    Wz[:, Ka:] = 0
+    check(A, A2, Wz, a_col0=128, c_col0=128)      # the quiet block alone decides the result: its own 11 bits, not the loud block's
+
+
+@pytest.mark.parametrize("I,J,K,w0", [(300, 512, 64, 30.0), (1000, 1024, 544, 1.0)])
+def test_one_plane_siren_forward_then_derivative_epilogue(I, J, K, w0, kc_grid):
+    g = torch.Generator().manual_seed(I + K)
+    X = (torch.rand(I, K, generator=g) * 2 - 1).to(DEV)
+    W = (torch.randn(J, K, generator=g) * (0.3 / K ** 0.5)).to(DEV)
+    b = (torch.randn(J, generator=g) * 0.1).to(DEV)
+    H, sign, _ = _kc(X, W, b, act=ACT_SIN, w0=w0, want_sign=True, c_col0=128, planes=1)
+    z = (X.double() @ W.double().T + b.double()) * w0
+    # operand rounding 2^-11 enters the sine's argument times |w0 z| ...
+    assert float((H.double() - torch.sin(z)).abs().max()) <= 2.0 ** -10 * (1.0 + float(z.abs().max())) + 2.0 ** -11
+    zh = torch.asin(H.double().clamp(-1, 1))       # ... the derivative epilogue rebuilds |cos| from the STORED h and takes its sign from the bits
+    Kg = 256
+    G = torch.randn(I, Kg, generator=g).to(DEV)
+    G[:128] *= 1e-7
+    W2 = (torch.randn(J, Kg, generator=g) * 0.05).to(DEV)
+    D, _, cs = _kc(G, W2, None, aux=AUX_SINREC, Hact=H, Hsign=sign, w0=w0, want_colsum=True, c_col0=128, planes=1)
+    cos_stored = torch.sqrt((1 - H.double() ** 2).clamp_min(0)) * torch.sign(torch.cos(z))
+    ref = (G.double() @ W2.double().T) * (w0 * cos_stored)
+    # entries where cos(z) is within the forward's own error of zero may carry either sign: compare rows in the norm
+    rows = (D.double() - ref).norm(dim=1) / ref.norm(dim=1)
+    assert float(rows.max()) <= 2e-2, float(rows.max())
+    assert float(rows[:128].max()) <= 2e-2
+
+
+def test_one_plane_relu_forward_and_mask(kc_grid):
+    g = torch.Generator().manual_seed(11)
+    I, J, K = 520, 256, 96
+    X = torch.randn(I, K, generator=g).to(DEV)
+    W = torch.randn(J, K, generator=g).to(DEV)
+    H, _, _ = _kc(X, W, None, act=ACT_RELU, planes=1)
+    z = X.double() @ W.double().T
+    assert _relerr(H, torch.relu(z)) <= 2.0 * _err16(X, W, z) + 2.0 ** -11
+    G = torch.randn(I, 64, generator=g).to(DEV)
+    W2 = torch.randn(J, 64, generator=g).to(DEV)
+    D, _, _ = _kc(G, W2, None, aux=AUX_RELU_MASK, Hact=H, planes=1)
+    want = (G.double() @ W2.double().T) * (H.double() > 0)
+    assert _relerr(D, want) <= 2.0 * _err16(G, W2, G.double() @ W2.double().T) + 2.0 ** -11
+
+
+@pytest.mark.parametrize("I,K", [(300, 512), (1000, 768), (129, 32), (257, 528)])
+def test_one_plane_kc_narrow_fp32_output(I, K):
+    g = torch.Generator().manual_seed(I)
+    A = torch.randn(I, K, generator=g)
+    A[:100] *= 1e-5
+    W = torch.randn(9, K, generator=g) * 0.1
+    b = torch.randn(9, generator=g)
+    A, W, b = A.to(DEV), W.to(DEV), b.to(DEV)
+    C0, _, _ = _kc(A, W, None, narrow=True, planes=1)
+    ref0 = A.double() @ W.double().T
+    rows = (C0[:, :9].double() - ref0).norm(dim=1) / ref0.norm(dim=1)
+    assert float(rows.max()) <= 3e-3, float(rows.max())           # the quiet rows as accurate as the loud ones
+    Cm, _, _ = _kc(A, W, b, narrow=True, planes=1)
+    assert float((Cm[:, :9].double() - (ref0 + b.double())).abs().max()) <= 3e-3 * float(ref0.abs().max())
+
+
+@pytest.mark.parametrize("P,I,J,ks", [(2048, 256, 256, 1024), (5000, 512, 544, 1024), (650, 256, 64, 128), (20000, 1024, 528, 4096), (1000, 256, 256, 1024)])
+def test_one_plane_dw(P, I, J, ks):
+    g = torch.Generator().manual_seed(P + I)
+    A = torch.randn(P, I, generator=g)
+    B = torch.randn(P, J, generator=g)
+    scale = torch.ones(P)
+    scale[: P // 3] = 2.0 ** -18
+    scale[P // 3: P // 2] = 2.0 ** 6
+    A = (A * scale[:, None]).to(DEV)
+    B = B.to(DEV)
+    Cm = _dw(A, B, I, J, k_split=ks, planes=1)
+    ref = A.double().T @ B.double()
+    err16 = _relerr(A.half().double().T @ B.half().double(), ref)
+    assert _relerr(Cm, ref) <= 2.0 * err16 + 1e-6, (_relerr(Cm, ref), err16)
+
+
+def test_one_plane_dw_column_offsets_and_narrow():
+    g = torch.Generator().manual_seed(3)
+    P = 3000
+    A = torch.randn(P, 384, generator=g).to(DEV)
+    B = torch.randn(P, 448, generator=g).to(DEV)
+    Cm = _dw(A, B, 256, 320, a_col0=128, b_col0=128, planes=1)
+    ref = A[:, 128:384].double().T @ B[:, 128:448].double()
+    assert _relerr(Cm, ref) <= 1e-3
+    An = torch.randn(P, 32, generator=g).to(DEV)
+    An[:1000] *= 1e-6
+    Cn = _dw(An, B, 32, 448, narrow=True, planes=1)
+    refn = An.double().T @ B.double()
+    assert _relerr(Cn, refn) <= 1e-3
+    Cn2 = _dw(An, B, 9, 200, b_col0=192, narrow=True, planes=1)
+    assert _relerr(Cn2, An[:, :9].double().T @ B[:, 192:392].double()) <= 1e-3

@@ -124,7 +124,6 @@ def test_c3_semantic_car_reg_4096x96_default_arithmetic():
     assert "coarse_car_reg_loss" in ld and torch.isfinite(ld["coarse_car_reg_loss"])
 
 
-@pytest.mark.legacy_arithmetic
 def test_c3_semantic_car_reg_4096x96_bf16(monkeypatch):
     """configs[2] in the arithmetic BASELINE names for it (bf16, the reference's precision = 16): REDUCED precision,
     judged PSNR-style -- outputs within 2e-2 (PSNR of the rendered colours against the fp32 oracle > 40 dB), loss terms
@@ -141,7 +140,6 @@ def test_c4_semantic_2048x128():
     _subset_parity(cfg, 2048, 128, seed=25, epoch=2)
 
 
-@pytest.mark.legacy_arithmetic
 def test_c5_semantic_4096x128_bf16(monkeypatch):
     """configs[4] per-GPU training shape (32768 x 128 over 8 GPUs, bf16): 524 k points per pass; REDUCED-precision bar as
     in test_c3_*_bf16 (UNPINNED, see there).  (The configuration's full-frame inference half:

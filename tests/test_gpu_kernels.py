@@ -28,77 +28,6 @@ def _dev():
 
 
 # ----------------------------------------------------------------------------------------------------
-# the round-1 GEMMs (csrc/legacy/) in isolation: fp32 MFMA and split-bf16 planes -- behind the arithmetic flags, not the default
-# ----------------------------------------------------------------------------------------------------
-@pytest.mark.legacy_arithmetic
-@pytest.mark.parametrize("a_ic,b_ic,narrow,I,J,K", [
-    (0, 0, 0, 128, 128, 32), (0, 0, 0, 256, 512, 512), (0, 0, 0, 200, 100, 60), (0, 0, 0, 1000, 520, 572),
-    (0, 0, 1, 384, 32, 768), (0, 0, 1, 77, 32, 16),
-    (0, 1, 0, 256, 512, 512), (0, 1, 0, 300, 524, 1024), (0, 1, 0, 130, 256, 32),
-    (1, 1, 0, 512, 512, 1024), (1, 1, 0, 256, 60, 777), (1, 1, 2, 32, 768, 1500), (1, 1, 0, 1024, 524, 64),
-])
-def test_gemm_layouts(a_ic, b_ic, narrow, I, J, K):
-    _gemm_case(a_ic, b_ic, narrow, I, J, K)
-
-
-@pytest.mark.legacy_arithmetic
-@pytest.mark.parametrize("a_ic,b_ic,I,J,K", [
-    (0, 0, 128, 128, 16), (0, 0, 256, 512, 512), (0, 0, 200, 100, 60), (0, 0, 1000, 520, 576), (0, 0, 77, 36, 1024),
-    (1, 1, 128, 128, 32), (1, 1, 512, 512, 1024), (1, 1, 256, 60, 777), (1, 1, 1024, 524, 64), (1, 1, 36, 300, 5000),
-])
-def test_gemm_split_bf16(a_ic, b_ic, I, J, K):
-    """split-bf16 (3 planes, 6 MFMA products) GEMM: exact on small integers, fp32-level error on random data"""
-    _gemm_case(a_ic, b_ic, 4, I, J, K)
-
-
-@pytest.mark.legacy_arithmetic
-@pytest.mark.parametrize("a_ic,b_ic,I,J,K", [(0, 0, 300, 256, 144), (1, 1, 256, 200, 1000)])
-@pytest.mark.parametrize("mode,tol", [(8, 3e-2), (16, 2e-4)])
-def test_gemm_reduced_planes(a_ic, b_ic, I, J, K, mode, tol):
-    """REDUCED-precision plane counts of the split kernel (SNERF_FLAG_BF16 = 1 plane, SNERF_FLAG_BF16X3 = 2 planes):
-    still exact on small integers (bf16-representable), random data within the operand rounding (2^-9 resp. 2^-17
-    relative per operand, accumulated over K in fp32)."""
-    from snerf_amd import ops
-    dev = _dev()
-    g = torch.Generator().manual_seed(11)
-    A = torch.randint(-3, 4, (I, K), generator=g).float()
-    B = torch.randint(-3, 4, (J, K), generator=g).float()
-    lay = lambda M, ic: (M.T.contiguous() if ic else M).to(dev)
-    C = ops.test_gemm(lay(A, a_ic), lay(B, b_ic), bool(a_ic), bool(b_ic), I, J, K, 4 | mode).cpu()
-    assert torch.equal(C, (A.double() @ B.double().T).float())
-    A = torch.randn(I, K, generator=g)
-    B = torch.randn(J, K, generator=g)
-    ref = A.double() @ B.double().T
-    C = ops.test_gemm(lay(A, a_ic), lay(B, b_ic), bool(a_ic), bool(b_ic), I, J, K, 4 | mode).cpu().double()
-    err = float((C - ref).abs().max() / ref.abs().max())
-    assert err <= tol, err
-    full = ops.test_gemm(lay(A, a_ic), lay(B, b_ic), bool(a_ic), bool(b_ic), I, J, K, 4).cpu().double()
-    assert float((full - ref).abs().max()) < float((C - ref).abs().max())  # and the 3-plane form is tighter
-
-
-def _gemm_case(a_ic, b_ic, narrow, I, J, K):
-    from snerf_amd import ops
-    dev = _dev()
-    g = torch.Generator().manual_seed(I * 7 + J * 3 + K)
-    # asymmetric integer-valued operands catch transposed / permuted fragment maps exactly
-    A = torch.randint(-3, 4, (I, K), generator=g).float()
-    B = torch.randint(-3, 4, (J, K), generator=g).float()
-    ref = (A.double() @ B.double().T).float()
-    Ad = (A.T.contiguous() if a_ic else A).to(dev)
-    Bd = (B.T.contiguous() if b_ic else B).to(dev)
-    C = ops.test_gemm(Ad, Bd, bool(a_ic), bool(b_ic), I, J, K, narrow).cpu()
-    assert torch.equal(C, ref), f"max diff {(C - ref).abs().max()}"
-    # random fp32 operands: fp32 accumulate, error ~1e-6 relative
-    A = torch.randn(I, K, generator=g)
-    B = torch.randn(J, K, generator=g)
-    ref = (A.double() @ B.double().T)
-    Ad = (A.T.contiguous() if a_ic else A).to(dev)
-    Bd = (B.T.contiguous() if b_ic else B).to(dev)
-    C = ops.test_gemm(Ad, Bd, bool(a_ic), bool(b_ic), I, J, K, narrow).cpu().double()
-    assert (C - ref).abs().max() <= 2e-5 * max(1.0, float(ref.abs().max()))
-
-
-# ----------------------------------------------------------------------------------------------------
 # one rendering pass vs the oracle
 # ----------------------------------------------------------------------------------------------------
 def _gpu_params(params_np, dev, requires_grad=False):
@@ -318,70 +247,46 @@ def test_ragged_and_multi_chunk_sizes():
         assert rel_err(emb_g.grad.cpu(), emb_o.grad) <= GRAD_REL_TOL
 
 
-@pytest.mark.legacy_arithmetic
-def test_reduced_precision_modes_full_width(monkeypatch):
-    """REDUCED-precision modes at the headline width (sem_siren_full fixture): `split2` (two bf16 planes, torch's "high")
-    stays inside the 1e-4 output bar with gradients ~1e-4 relative; `bf16` (one plane, precision = 16 / "medium") is
-    the PSNR/mIoU-judged mode -- outputs within 2e-2, losses within 1 %.  Neither is the default."""
+REDUCED_STATS = []   # measured errors of the one-plane mode (printed by tests/conftest.py's summary hook when present)
+
+
+def test_reduced_precision_mode_full_width(monkeypatch):
+    """SNERF_FLAG_F16X1 -- one fp16 plane of the block-scaled tensors, one product: the mode of the reference's `precision = 16`
+    runs (BASELINE.json configs[2] / [4]) -- at the headline width on the reference's own W = 512 fixture, through the SAME kernels
+    as the default (templated on the plane count).  REDUCED precision: the bars below are this build's own, UNPINNED (the
+    reference publishes no half-precision numbers and runs no such path here): outputs 5e-3 absolute (measured 7.4e-4), loss terms 1 %,
+    gradients within 10 % relative L2 of the default arithmetic's (measured 3.8 %) and finite.  The default is held to 1e-4 / 2e-4 right above."""
     from snerf_amd import ops, _lib
     dev = _dev()
     z, meta, cfg = load_fixture("sem_siren_full")
     pn = fixture_params(z, meta, cfg)
     b = fixture_batch(z)
-    grads = {}
-    outs = {}
-    for name, flags, out_tol, loss_tol in (("split3", _lib.FLAG_SPLIT3, OUT_TOL, 2e-4), ("split2", _lib.FLAG_BF16X3, 1e-4, 2e-4),
-                                           ("bf16", _lib.FLAG_BF16, 2e-2, 1e-2),
-                                           ("split3_bwd2", _lib.FLAG_BWD_BF16X3, OUT_TOL, 2e-4)):
+    grads, outs = {}, {}
+    for name, flags, out_tol, loss_tol in (("f16x2", 0, OUT_TOL, 2e-4), ("f16x1", _lib.FLAG_F16X1, 5e-3, 1e-2)):
         monkeypatch.setattr(ops, "BASE_FLAGS", flags)
         gp = _gpu_params(pn, dev, requires_grad=True)
         emb_g = torch.from_numpy(O.init_embedding_numpy(cfg, meta["seed"])).to(dev).requires_grad_(True)
         hip = _hip_render(cfg, gp, emb_g, b, dev)
         hip.pop("_z_vals")
+        worst = 0.0
         for k in z.files:
             if k.startswith("out_") and k != "out_semantic_label_coarse":
-                assert max_abs(hip[k[4:]].detach().cpu(), z[k]) <= out_tol, (name, k)
+                e = max_abs(hip[k[4:]].detach().cpu(), z[k])
+                worst = max(worst, e)
+                assert e <= out_tol, (name, k, e)
         bg = {k: v.to(dev) for k, v in b.items()}
         ld = O.training_losses(hip, bg, cfg, meta["epoch"])
         for k in ld:
             ref = float(z["loss_" + k])
-            assert abs(float(ld[k].detach()) - ref) <= loss_tol * max(1.0, abs(ref)), (name, k)
+            assert abs(float(ld[k].detach()) - ref) <= loss_tol * max(1.0, abs(ref)), (name, k, float(ld[k].detach()), ref)
         O.total_loss(ld).backward()
         grads[name] = {k: v.grad.clone().cpu() for k, v in gp.items()}
-        outs[name] = {k: v.detach().cpu() for k, v in hip.items()}
-    # backward-only reduction: the forward is the default one bit for bit, the gradients are the two-plane ones
-    assert all(torch.equal(outs["split3_bwd2"][k], outs["split3"][k]) for k in outs["split3"])
-    assert max(float(rel_err(grads["split3_bwd2"][k], grads["split3"][k])) for k in grads["split3"]) <= 1e-3
-    worst2 = max(float(rel_err(grads["split2"][k], grads["split3"][k])) for k in grads["split3"])
-    assert worst2 <= 1e-3, worst2
-    assert all(torch.isfinite(g).all() for g in grads["bf16"].values())
-
-
-def test_fp32_mfma_flag_path(monkeypatch):
-    """SNERF_FLAG_FP32_MFMA (plain v_mfma_f32_32x32x2_f32 kernels) gives the same results as the split-bf16 (split3) path"""
-    from snerf_amd import ops, _lib
-    dev = _dev()
-    z, meta, cfg = load_fixture("sem_siren_small")
-    pn = fixture_params(z, meta, cfg)
-    b = fixture_batch(z)
-    emb = torch.from_numpy(O.init_embedding_numpy(cfg, meta["seed"]))
-    outs = {}
-    for name, flags in (("x6", _lib.FLAG_SPLIT3), ("fp32", _lib.FLAG_FP32_MFMA)):
-        monkeypatch.setattr(ops, "BASE_FLAGS", flags)
-        gp = _gpu_params(pn, dev, requires_grad=True)
-        emb_g = emb.clone().to(dev).requires_grad_(True)
-        hip = _hip_render(cfg, gp, emb_g, b, dev)
-        hip.pop("_z_vals")
-        bg = {k: v.to(dev) for k, v in b.items()}
-        O.total_loss(O.training_losses(hip, bg, cfg, meta["epoch"])).backward()
-        outs[name] = (hip, {k: v.grad.clone() for k, v in gp.items()})
-        for k in z.files:
-            if k.startswith("out_") and k != "out_semantic_label_coarse":
-                assert max_abs(hip[k[4:]].detach().cpu(), z[k]) <= OUT_TOL, (name, k)
-    for k in outs["x6"][1]:
-        assert rel_err(outs["x6"][1][k].cpu(), outs["fp32"][1][k].cpu()) <= 1e-4 or \
-            max_abs(outs["x6"][1][k].cpu(), outs["fp32"][1][k].cpu()) <= 1e-8, k
-    assert max_abs(outs["x6"][0]["rgb_coarse"].detach().cpu(), outs["fp32"][0]["rgb_coarse"].detach().cpu()) <= 2e-6
+        outs[name] = worst
+    assert all(torch.isfinite(g).all() for g in grads["f16x1"].values())
+    rel = {k: float(rel_err(grads["f16x1"][k], grads["f16x2"][k])) for k in grads["f16x2"] if float(grads["f16x2"][k].abs().max()) > 0}
+    REDUCED_STATS.append({"worst_output_abs_err": outs["f16x1"], "worst_grad_rel_l2": max(rel.values()), "default_worst_output_abs_err": outs["f16x2"]})
+    print("f16x1 at W=512:", REDUCED_STATS[-1])
+    assert max(rel.values()) <= 1e-1, sorted(rel.items(), key=lambda kv: -kv[1])[:3]
 
 
 def test_forward_backward_capture_in_a_hip_graph():

@@ -12,14 +12,12 @@ def test_mfma_mode_mapping():
     from types import SimpleNamespace as NS
     from snerf_amd import ops, _lib
     assert ops.mfma_mode(NS(precision=32), None) == "f16x2"
-    assert ops.mfma_mode(NS(precision=16), None) == "bf16"
-    assert ops.mfma_mode(NS(precision=32, mfma_precision="fp32"), None) == "fp32"
-    for run, want in (("highest", "split3"), ("high", "split2"), ("medium", "bf16")):
+    assert ops.mfma_mode(NS(precision=16), None) == "f16x1"               # the reference's half-precision knob (baseline/pipelines/nerf.py:65)
+    assert ops.mfma_mode(NS(precision=32, mfma_precision="bf16"), None) == "f16x1"   # BASELINE.json's name for the same mode
+    for run, want in (("highest", "f16x2"), ("high", "f16x1"), ("medium", "f16x1")):
         assert ops.mfma_mode(NS(precision=32, mfma_precision="auto"), NS(float32_matmul_precision=run)) == want
-    d = ops.ModelSpec(mfma="split2").desc(16, 8)
-    assert d.flags & _lib.FLAG_BF16X3
+    assert ops.ModelSpec(mfma="f16x1").desc(16, 8).flags == _lib.FLAG_F16X1 == ops.ModelSpec(mfma="bf16").desc(16, 8).flags
     assert ops.ModelSpec().desc(16, 8).flags == 0                        # default: no arithmetic bit = f16x2 (C callers too)
-    assert ops.ModelSpec(mfma="split3").desc(16, 8).flags == _lib.FLAG_SPLIT3
 
 import torch
 

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Isolated launches of the block-scaled plane GEMMs at the headline layer shape (262,144 points x 512 x 512) through the
 test hooks -- run under `rocprofv3 --kernel-trace --stats` to read per-kernel durations (the hooks themselves allocate
-and convert, so wall time here means nothing)."""
+and convert, so wall time here means nothing).
+
+    python tools/bsp_kernel_bench.py <reps> <all|kc|fwd|plain|dx|dw|narrow> [planes = 2 | 1]"""
 import ctypes as C
 import os
 import sys
@@ -20,6 +22,7 @@ Wm = (torch.randn(W, W, generator=g) * 0.06).to(dev)
 b = torch.zeros(W, device=dev)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 which = sys.argv[2] if len(sys.argv) > 2 else "all"
+planes = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 
 
 def p(t):
@@ -30,29 +33,20 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 H = torch.empty(P, W, device=dev)
 sign = torch.zeros((P // 32) * (W // 64) * 64, dtype=torch.int32, device=dev)
 cs = torch.zeros(P // 32, W, device=dev)
-for _ in range(reps if which in ("all", "kc", "fwd") else 1):   # forward SIREN layer
-    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), None if which == "stamp" else p(b), P, W, W, 0, 0, 1, 1.0, 0, None, None, p(H), p(sign),
-                                   p(cs) if which == "stamp" else None, 0, st), "fwd")
-if which == "stamp":   # ablation build -DBSP_ABL_STAMP: per-workgroup (start, loop end, end, HW_ID, XCC_ID) in the colsum buffer
-    import numpy as np
-    d = cs.view(torch.int64).reshape(-1)[: 8 * 4096 + 4 * 512].cpu().numpy()
-    np.save(os.environ.get("STAMP_OUT", "gpurun_out/stamps.npy"), d)
+for _ in range(reps if which in ("all", "kc", "fwd") else 1):   # forward SIREN layer (always once: the dX launches need H and the sign words)
+    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), p(b), P, W, W, 0, 0, 1, 1.0, 0, None, None, p(H), p(sign), None, 0, planes, st), "fwd")
 for _ in range(reps if which in ("plain",) else 0):   # forward layer without activation
-    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), p(b), P, W, W, 0, 0, 0, 1.0, 0, None, None, p(H), None, None, 0, st), "plain")
+    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), p(b), P, W, W, 0, 0, 0, 1.0, 0, None, None, p(H), None, None, 0, planes, st), "plain")
 G = torch.randn(P, W, generator=g).to(dev) * 1e-3
 D = torch.empty(P, W, device=dev)
-dbg = torch.zeros(8 * 4096, dtype=torch.int64, device=dev) if which == "stampdx" else None
-for _ in range(reps if which in ("all", "kc", "dx", "stampdx") else 0):   # dX with the derivative epilogue + bias-gradient column sums
-    _lib.check(L.snerf_test_bsp_kc(p(G), None, W, p(Wm), None, P, W, W, 0, 0, 0, 1.0, 3, p(H), p(sign), p(D), p(dbg), p(cs), 0, st), "dx")
-if which == "stampdx":
-    import numpy as np
-    np.save(os.environ.get("STAMP_OUT", "gpurun_out/stamps.npy"), dbg.reshape(4096, 8).cpu().numpy())
+for _ in range(reps if which in ("all", "kc", "dx") else 0):   # dX with the derivative epilogue + bias-gradient column sums
+    _lib.check(L.snerf_test_bsp_kc(p(G), None, W, p(Wm), None, P, W, W, 0, 0, 0, 1.0, 3, p(H), p(sign), p(D), None, p(cs), 0, planes, st), "dx")
 Cw = torch.empty(W, W, device=dev)
 for _ in range(reps if which in ("all", "dw") else 0):   # dW, 64 splits
-    _lib.check(L.snerf_test_bsp_dw(p(G), W, p(X), W, P, W, W, 0, 0, 4096, 0, p(Cw), st), "dw")
+    _lib.check(L.snerf_test_bsp_dw(p(G), W, p(X), W, P, W, W, 0, 0, 4096, 0, p(Cw), planes, st), "dw")
 S32 = torch.empty(P, 32, device=dev)
 W32 = (torch.randn(32, W, generator=g) * 0.05).to(dev)
 for _ in range(reps if which in ("all", "narrow") else 0):   # 32-wide head
-    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(W32), None, P, 32, W, 0, 0, 0, 1.0, 0, None, None, p(S32), None, None, 1, st), "narrow")
+    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(W32), None, P, 32, W, 0, 0, 0, 1.0, 0, None, None, p(S32), None, None, 1, planes, st), "narrow")
 torch.cuda.synchronize()
 print("ok")

@@ -7,7 +7,7 @@ from bench import make_cfgs
 from snerf_amd.framework.pipelines import load_pipeline, TrainLoop
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-modes = sys.argv[2:4] if len(sys.argv) > 3 else ["split3", "f16x2"]
+modes = sys.argv[2:4] if len(sys.argv) > 3 else ["f16x1", "f16x2"]
 dev = torch.device("cuda:0")
 curves = {}
 for m in modes:
