@@ -37,7 +37,8 @@ if "to_planes_kernel" in iso_f:
     cal["write_bytes_per_unit"] = KNOWN / avg(iso_w["to_planes_kernel"]["WRITE_SIZE"])
 print("calibration (bytes per counter unit, from to_planes: %d B each way):" % KNOWN, cal)
 out = {"calibration": cal, "known_bytes_to_planes": KNOWN, "kernels": {}}
-for tag, ff, ww in (("isolated 262144x512x512", iso_f, iso_w), ("bench step", per_kernel("step_fetch"), per_kernel("step_write"))):
+for tag, ff, ww in (("isolated 262144x512x512", iso_f, iso_w), ("isolated 262144x512x512, one plane", per_kernel("iso1_fetch"), per_kernel("iso1_write")),
+                    ("bench step", per_kernel("step_fetch"), per_kernel("step_write"))):
     print("==", tag)
     for k in sorted(ff, key=lambda k: -sum(ff[k]["FETCH_SIZE"])):
         f = avg(ff[k]["FETCH_SIZE"]) * cal.get("fetch_bytes_per_unit", 0.0)
@@ -52,7 +53,12 @@ kc = [(v["launches"], v["read_bytes"] + v["written_bytes"]) for k, v in step.ite
 if kc:
     out["kc_bytes_per_launch"] = sum(n * b for n, b in kc) / sum(n for n, _ in kc)
     print("gemm_kc_kernel, bench step: %.1f MB per launch (launch-weighted over its variants)" % (out["kc_bytes_per_launch"] / 1e6))
-for sub in ("iso_sq", "iso_sq2", "step_sq"):
+out["bench_steps_profiled"] = 5      # `bench.py --steps 3 --warmup 2`: every launch of the process is in the trace
+tot = sum((v["read_bytes"] + v["written_bytes"]) * v["launches"] for v in step.values()) / out["bench_steps_profiled"] if step else 0.0
+if tot:
+    out["step_hbm_bytes"] = tot
+    print("whole bench step: %.1f GB of HBM traffic (read + written, all kernels)" % (tot / 1e9))
+for sub in ("iso_sq", "iso_sq2", "iso1_sq", "iso1_sq2", "step_sq"):
     a = per_kernel(sub)
     print("==", sub)
     for k, c in a.items():
@@ -67,5 +73,5 @@ try:
 except Exception:
     out["commit"] = os.environ.get("SNERF_COMMIT")
 out["provenance"] = ("tools/pmc_traffic.sh on one MI355X (gpurun box): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in passes of their own over "
-                     "`bench.py --steps 3 --warmup 2 --serial-passes` and over isolated launches; units calibrated on to_planes (known bytes)")
+                     "`bench.py --steps 3 --warmup 2 --serial-passes --no-reduced` and over isolated launches (both plane counts); units calibrated on to_planes (known bytes)")
 json.dump(out, open(os.path.join(d, "pmc_hbm_traffic.json"), "w"), indent=1)
