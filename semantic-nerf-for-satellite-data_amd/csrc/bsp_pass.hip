@@ -296,15 +296,20 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
   char* dz = ws.c(p.o_dza); int* edz = ws.i(p.e_dza);   // dz1 is dead from here on
   {  // 4. feats + sigma: dW for the [W + 32][W] matrix, then dz of the last trunk layer
     const char* hl = ws.c(p.o_h[p.L - 1]); const int* ehl = ws.i(p.e_h[p.L - 1]);
-    RC(narrow_grad(p, rq, dsig, ws.c(p.o_pdsig), ws.i(p.e_dsig), gp + p.b_fs + W, st));
+    // The density branch carries a gradient only if one reaches weights / transparency (/ sigmas, depth, rgb, logits in the main
+    // pass).  In the solar-correction pass of a training step none does: the loss detaches T' and w' (baseline/components/loss.py:8-10)
+    // and the composite backward then writes d sigma = 0 exactly -- its bias sums, its dW launch and the 32 extra contraction columns
+    // of the dX launch are skipped (SURVEY 8(d) counts the sc backward "through sun_v / feats / trunk only").
+    const bool sig_live = !p.sc || go->weights != nullptr || go->transparency != nullptr || go->sigmas != nullptr;
+    if (sig_live) RC(narrow_grad(p, rq, dsig, ws.c(p.o_pdsig), ws.i(p.e_dsig), gp + p.b_fs + W, st));
     const DwMat ms = dw_begin(p, rq, W + NARROW, W, W, false);
     RC(dw_gemm(p, ms, dfa, edfa, p.FA, 0, W, false, hl, ehl, W, 0, W, 0, st));
-    RC(dw_gemm(p, ms, ws.c(p.o_pdsig), ws.i(p.e_dsig), NARROW, 0, NARROW, true, hl, ehl, W, 0, W, (size_t)W * W, st));
-    RC(dw_reduce(rq, ms, (size_t)(W + NARROW) * W, gp + p.w_fs));
+    if (sig_live) RC(dw_gemm(p, ms, ws.c(p.o_pdsig), ws.i(p.e_dsig), NARROW, 0, NARROW, true, hl, ehl, W, 0, W, (size_t)W * W, st));
+    RC(dw_reduce(rq, ms, (size_t)(sig_live ? W + NARROW : W) * W, gp + p.w_fs));
     bsp::KcArgs g;
     g.A = dfa; g.EA = edfa; g.lda = p.FA; g.Ka = W;
-    g.A2 = ws.c(p.o_pdsig); g.EA2 = ws.i(p.e_dsig); g.lda2 = NARROW;
-    weights(g, p, pk, p.wj_tfs); g.I = P; g.J = W; g.K = W + NARROW;
+    if (sig_live) { g.A2 = ws.c(p.o_pdsig); g.EA2 = ws.i(p.e_dsig); g.lda2 = NARROW; }
+    weights(g, p, pk, p.wj_tfs); g.I = P; g.J = W; g.K = sig_live ? W + NARROW : W;
     g.C = dz; g.EC = edz; g.ldc = W;
     dact(g, p.o_c[p.L - 1], p.o_h[p.L - 1], p.e_h[p.L - 1], W, 0, (p.L == 1) ? 30.f : 1.f);
     cs_ = colsum(g, W);
