@@ -182,6 +182,14 @@ def reduced_precision_leg(rays, samples, device, steps=10, warmup=4):
     res = {"mode": "f16x1", "dtype": "f16 (one block-scaled fp16 plane; REDUCED)", "rays": rays, "samples": samples, "rays_per_s": rays / dt,
            "ms_per_step": dt * 1e3, "steps": steps, "final_loss": float(out["loss"].detach()),
            "config": "configs[2] shape (semantic + L_t)" if samples == 96 else "configs[4] per-GPU shape"}
+    if samples == 128:      # configs[4]'s second half: full-frame forward-only rendering (eval/extract_pointcloud.py) in the same mode
+        del loop, out
+        ops.release_workspaces()
+        torch.cuda.empty_cache()
+        inf = inference_rates(pipe, cfgs, device, samples, n_rays=40960 * 2)
+        res["lean_inference_rays_per_s"] = inf["lean_rays_per_s"]
+        res["lean_inference_rays"] = inf["rays"]
+        loop = out = None
     del loop, pipe, out
     ops.release_workspaces()
     torch.cuda.empty_cache()
