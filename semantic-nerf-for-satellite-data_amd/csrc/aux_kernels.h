@@ -28,12 +28,15 @@ int launch_reduce_rows(const float* in, int n_in, size_t in_stride, int width, f
                        int group, int accumulate, hipStream_t st);
 int reduce_partials(const float* in, int n_in, size_t in_stride, int width, float* tmp, float* out, hipStream_t st);
 // batched reductions (aux_kernels.hip): out[e] += sum_q in[q * stride + e], all jobs of a pass in two launches
-struct RedJob { const float* in; float* out; unsigned long long stride; long long width; int n_in; int blk0; int vec; int pad; };
+// (cols / in_ld / out_ld: a 2-D job -- element e = r * cols + c lies at in[q * stride + r * in_ld + c] and goes to out[r * out_ld + c];
+//  1-D jobs have cols = width)
+struct RedJob { const float* in; float* out; unsigned long long stride; long long width; int n_in; int blk0; int vec; int cols; int in_ld; int out_ld; int pad[2]; };
 constexpr int RED_MAX = 56;
 struct RedTable { RedJob j[RED_MAX]; int n = 0; int blocks = 0; };      // host-side queue
 constexpr int RED_CHUNK = 24;
 struct RedChunk { RedJob j[RED_CHUNK]; int n = 0; };                      // what one launch carries as its argument
 int red_add_elem(RedTable& tb, const float* in, int n_in, size_t stride, size_t width, float* out);   // few slabs, many elements
+int red_add_elem2d(RedTable& tb, const float* in, int n_in, size_t stride, int rows, int cols, int in_ld, float* out, int out_ld);   // a column block of a wider matrix
 int red_add_col(RedTable& tb, const float* in, int n_in, size_t stride, int width, float* out);       // many partial rows, <= ~1024 columns
 int launch_reductions(const RedTable& elem, const RedTable& col, hipStream_t st);
 int launch_embedding_rows(const float* table, int n_embed, int tau, const long long* idx, int n, float* rows, hipStream_t st);

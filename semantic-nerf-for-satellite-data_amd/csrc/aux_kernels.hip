@@ -206,8 +206,12 @@ __global__ __launch_bounds__(256) void reduce_elem_jobs_kernel(const RedChunk tb
   int k = 0;
   while (k + 1 < tb.n && (int)blockIdx.x >= tb.j[k + 1].blk0) ++k;
   const RedJob jb = tb.j[k];
-  const size_t e = ((size_t)(blockIdx.x - jb.blk0) * 256 + threadIdx.x) * (jb.vec ? 4 : 1);
-  if (e >= (size_t)jb.width) return;
+  const size_t e0 = ((size_t)(blockIdx.x - jb.blk0) * 256 + threadIdx.x) * (jb.vec ? 4 : 1);
+  if (e0 >= (size_t)jb.width) return;
+  // 2-D jobs (a column block of a wider matrix): row / column of the element (a vector of four never straddles a row: cols % 4 == 0)
+  const size_t r = e0 / (size_t)jb.cols, cc = e0 - r * (size_t)jb.cols;
+  const size_t e = jb.cols == jb.width ? e0 : r * (size_t)jb.in_ld + cc;
+  const size_t eo = jb.cols == jb.width ? e0 : r * (size_t)jb.out_ld + cc;
   if (jb.vec) {
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
     int q = 0;
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256) void reduce_elem_jobs_kernel(const RedChunk tb
       s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
     }
     if (q < jb.n_in) { const float4 a = *reinterpret_cast<const float4*>(jb.in + (size_t)q * jb.stride + e); s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
-    float4* o = reinterpret_cast<float4*>(jb.out + e);
+    float4* o = reinterpret_cast<float4*>(jb.out + eo);
     float4 v = *o;
     v.x += s0.x + s1.x; v.y += s0.y + s1.y; v.z += s0.z + s1.z; v.w += s0.w + s1.w;
     *o = v;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256) void reduce_elem_jobs_kernel(const RedChunk tb
     int q = 0;
     for (; q + 1 < jb.n_in; q += 2) { s0 += jb.in[(size_t)q * jb.stride + e]; s1 += jb.in[(size_t)(q + 1) * jb.stride + e]; }
     if (q < jb.n_in) s0 += jb.in[(size_t)q * jb.stride + e];
-    jb.out[e] += s0 + s1;
+    jb.out[eo] += s0 + s1;
   }
 }
 
@@ -264,8 +268,21 @@ int red_add_elem(RedTable& tb, const float* in, int n_in, size_t stride, size_t 
   if (tb.n >= RED_MAX) { set_error("reduction queue full"); return SNERF_ERR_WORKSPACE; }
   RedJob& j = tb.j[tb.n++];
   j.in = in; j.out = out; j.stride = stride; j.n_in = n_in; j.width = (long long)width; j.blk0 = tb.blocks;
+  j.cols = (int)(width < 0x7fffffff ? width : 0x7fffffff); j.in_ld = j.out_ld = 0;
+  if ((long long)j.cols != j.width) { set_error("reduction job too wide"); return SNERF_ERR_WORKSPACE; }
   j.vec = ((width & 3) == 0 && (stride & 3) == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
   tb.blocks += (int)((width / (j.vec ? 4 : 1) + 255) / 256);
+  return 0;
+}
+int red_add_elem2d(RedTable& tb, const float* in, int n_in, size_t stride, int rows, int cols, int in_ld, float* out, int out_ld) {
+  if (n_in <= 0 || rows <= 0 || cols <= 0) return 0;
+  if (cols == in_ld && cols == out_ld) return red_add_elem(tb, in, n_in, stride, (size_t)rows * cols, out);
+  if (tb.n >= RED_MAX) { set_error("reduction queue full"); return SNERF_ERR_WORKSPACE; }
+  RedJob& j = tb.j[tb.n++];
+  j.in = in; j.out = out; j.stride = stride; j.n_in = n_in; j.width = (long long)rows * cols; j.blk0 = tb.blocks;
+  j.cols = cols; j.in_ld = in_ld; j.out_ld = out_ld;
+  j.vec = ((cols & 3) == 0 && (in_ld & 3) == 0 && (out_ld & 3) == 0 && (stride & 3) == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0) ? 1 : 0;
+  tb.blocks += (int)(((size_t)j.width / (j.vec ? 4 : 1) + 255) / 256);
   return 0;
 }
 int red_add_col(RedTable& tb, const float* in, int n_in, size_t stride, int width, float* out) {

@@ -195,7 +195,12 @@ size_t bsp_rq_floats(const Plan& p) {
   nar(); slab(NARROW, H, H, true); slab(H, H, H, false); slab(H, H, H, false); cs(H); cs(H); cs(H);
   slab(p.h1w, p.FA, p.FA, false); cs(p.FA);
   nar(); slab(W + NARROW, W, W, false); cs(W);
-  for (int i = p.L - 1; i >= 0; --i) { slab(W, p.k_tr[i], i == 0 ? p.Ep : W, false); if (i > 0) cs(W); }
+  for (int i = p.L - 1; i >= 0; --i) {
+    const bool skip = i > 0 && ((p.skip_mask >> i) & 1u);
+    if (skip) { slab(W, p.Ep, p.Ep, false); slab(W, W, W, false); }      // [gamma | h] columns: two slab regions (backward_bsp)
+    else slab(W, p.k_tr[i], i == 0 ? p.Ep : W, false);
+    if (i > 0) cs(W);
+  }
   return n;
 }
 
@@ -321,11 +326,21 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
   char* dz_nxt = ws.c(p.o_dzb); int* edz_nxt = ws.i(p.e_dzb);
   for (int i = p.L - 1; i >= 0; --i) {
     const bool skip = (p.skip_mask >> i) & 1u;
-    const int hoff = (i > 0 && skip) ? p.Ep : 0;  // column of the h part inside W_i
-    const DwMat mt = dw_begin(p, rq, W, p.k_tr[i], i == 0 ? p.Ep : W, false);
-    if (i == 0 || skip) RC(dw_gemm(p, mt, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_pe), ws.i(p.e_pe), p.Ep, 0, p.Ep, 0, st));
-    if (i > 0) RC(dw_gemm(p, mt, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_h[i - 1]), ws.i(p.e_h[i - 1]), W, 0, W, hoff, st));
-    RC(dw_reduce(rq, mt, (size_t)W * p.k_tr[i], gp + p.w_tr[i]));
+    if (i > 0 && skip) {
+      // skip layer W_i = [W_gamma (Ep columns) | W_h (W columns)]: the two column blocks are two contractions of very different
+      // width over the same dz, so each gets a slab region and a split count of its own (the 64-column block: two tiles x 128 splits;
+      // sharing the wide block's 64 splits left half the chip idle for it: 275 us against 180) and a 2-D reduction into its columns
+      const DwMat mg = dw_begin(p, rq, W, p.Ep, p.Ep, false), mh = dw_begin(p, rq, W, W, W, false);
+      RC(dw_gemm(p, mg, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_pe), ws.i(p.e_pe), p.Ep, 0, p.Ep, 0, st));
+      RC(dw_gemm(p, mh, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_h[i - 1]), ws.i(p.e_h[i - 1]), W, 0, W, 0, st));
+      RC(red_add_elem2d(rq.elem, mg.slab, mg.sp.ns, mg.stride, W, p.Ep, p.Ep, gp + p.w_tr[i], p.k_tr[i]));
+      RC(red_add_elem2d(rq.elem, mh.slab, mh.sp.ns, mh.stride, W, W, W, gp + p.w_tr[i] + p.Ep, p.k_tr[i]));
+    } else {
+      const DwMat mt = dw_begin(p, rq, W, p.k_tr[i], i == 0 ? p.Ep : W, false);
+      if (i == 0) RC(dw_gemm(p, mt, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_pe), ws.i(p.e_pe), p.Ep, 0, p.Ep, 0, st));
+      else RC(dw_gemm(p, mt, dz_cur, edz_cur, W, 0, W, false, ws.c(p.o_h[i - 1]), ws.i(p.e_h[i - 1]), W, 0, W, 0, st));
+      RC(dw_reduce(rq, mt, (size_t)W * p.k_tr[i], gp + p.w_tr[i]));
+    }
     if (i == 0) break;
     bsp::KcArgs g;
     g.A = dz_cur; g.EA = edz_cur; g.lda = W; g.Ka = W; weights(g, p, pk, p.wj_tt[i]);
