@@ -289,6 +289,11 @@ __global__ __launch_bounds__(TI == 256 ? 512 : 256, 2) void gemm_dw_kernel(const
       e_cur = e_new;
     }
   };
+  // A wave whose 64 columns (or 128 rows) lie entirely beyond J (I) contracts zeros: the 64-column block of a skip / first layer
+  // (J = 64: three of four column quarters), the 16 extras columns of the first head layer (J = 528: the third column tile).  It
+  // still issues its share of the stage requests and keeps every barrier, but reads no fragments and issues no MFMAs -- the
+  // matrix pipe and the LDS ports go to the co-resident waves (the other pass's launches under the two-stream schedule).
+  const bool active = (j0 + wj0 < p.J) && (i0 + wi0 < p.I);
   if constexpr (TI == 256) {
     // Ping-pong: the eight waves form two groups (tile rows 0-127 / 128-255; one wave of each per SIMD) that run the same
     // two-phase step -- M: request stage s + 2, read the 24 fragments of stage s | C: 24 MFMAs on those registers -- one
@@ -307,6 +312,7 @@ __global__ __launch_bounds__(TI == 256 ? 512 : 256, 2) void gemm_dw_kernel(const
     f16x8 fa_h[4], fa_l[4], fb_h[2], fb_l[2];
     auto phaseM = [&](int s, int slot) {
       issue(s + T::RING - 1, (slot + T::RING - 1) % T::RING);
+      if (!active) return;
       chunk(s);
       const char* st = lds + slot * T::STAGE;
 #pragma unroll
@@ -319,6 +325,7 @@ __global__ __launch_bounds__(TI == 256 ? 512 : 256, 2) void gemm_dw_kernel(const
       }
     };
     auto phaseC = [&]() {
+      if (!active) return;
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)

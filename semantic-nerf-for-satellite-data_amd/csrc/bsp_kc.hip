@@ -100,6 +100,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   // ---- state of the tile whose operands are being requested ------------------------------------------------------------
   int ti = 0, tj = 0, i0 = 0, j0 = 0, e_last = 0;
   unsigned w_u0 = 0;
+  // This wave's 64 columns of that tile lie beyond J (the thin last column tile of a launch with J = 528: three of its four waves): its
+  // weight loads are rejected through the scalar offset (before, they fetched the next k-step's units of other columns: a quarter of
+  // the launch's weight fills for nothing).  Everything else stays as it is -- same requests, waits, barriers: guarding the MFMAs and
+  // fragment reads too was tried (as branches inside the sub-step and as a second k-loop) and both made the kernel spill.
+  bool w_idle = false;
   int eA = 0, eB = 0;              // exponent of k-step (lane) / (lane + 64)
   float bias_t = 0.f;              // the tile's bias, one column per thread
   // The descriptor, the lanes' offsets and the stage bias of the segment being requested are loop-carried and replaced
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) voCur[q] = a_lane_off(q, lda, l);
     w_u0 = (unsigned)((a->w_row0 + j0 + wj0) >> 5);
+    w_idle = j0 + wj0 >= a->J;
     // exponents of the k-steps (lane) and (lane + 64) and of the last one: the fields of both segments as scalars, the choice per lane
     const int* EA1 = a->EA; const int* EA2 = a->EA2;
     const int ncb1 = ncb_of(lda), ncb2 = ncb_of(a->lda2), ac1 = a->a_col0, ac2 = a->a2_col0;
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     // (s_nop 4: a scalar operand the compiler has just restored from a spill lane (v_readlane) needs five wait states before
     //  a vector-memory instruction reads it, and nothing inside an asm statement is padded for us)
     if constexpr (PL == 2) {     // unit (16-k step s, 32-row block) = 2 KiB [hi | lo]; half: the wave's first / second 32-row block
-      const unsigned so = s < nks ? ((w_ks0 + (unsigned)s) * w_rb32 + w_u0) * 2048u : OOB;
+      const unsigned so = (s < nks && !w_idle) ? ((w_ks0 + (unsigned)s) * w_rb32 + w_u0) * 2048u : OOB;
       if (half == 0)
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024"
                      : "=&v"(b.h[0]), "=&v"(b.l[0]) : "v"(voW), "s"(srdW), "s"(so));
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
                      : "=&v"(b.h[1]), "=&v"(b.l[1]) : "v"(voW), "s"(srdW), "s"(so));
     } else {                     // units of 1 KiB; half: the first / second 16-k step of the 32-deep sub-step (h / l registers), both 32-row blocks
       const int s16 = 2 * s + half;
-      const unsigned so = s16 < nks16 ? ((w_ks0 + (unsigned)s16) * w_rb32 + w_u0) * 1024u : OOB;
+      const unsigned so = (s16 < nks16 && !w_idle) ? ((w_ks0 + (unsigned)s16) * w_rb32 + w_u0) * 1024u : OOB;
       if (half == 0)
         asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, %4 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen offset:1024"
                      : "=&v"(b.h[0]), "=&v"(b.h[1]) : "v"(voW), "s"(srdW), "s"(so));
