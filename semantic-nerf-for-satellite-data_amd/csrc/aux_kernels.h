@@ -39,6 +39,7 @@ int red_add_elem(RedTable& tb, const float* in, int n_in, size_t stride, size_t 
 int red_add_elem2d(RedTable& tb, const float* in, int n_in, size_t stride, int rows, int cols, int in_ld, float* out, int out_ld);   // a column block of a wider matrix
 int red_add_col(RedTable& tb, const float* in, int n_in, size_t stride, int width, float* out);       // many partial rows, <= ~1024 columns
 int launch_reductions(const RedTable& elem, const RedTable& col, hipStream_t st);
+int launch_ray_sum32(const float* d32, int col0, int N, int S, int tau, float* out, hipStream_t st);   // out[n][c] = sum_s d32[(n S + s)][col0 + c], rows of 32 floats
 int launch_embedding_rows(const float* table, int n_embed, int tau, const long long* idx, int n, float* rows, hipStream_t st);
 int launch_embedding_backward(const long long* idx, const float* d_rows, int n, int tau, int n_embed, float* grad, hipStream_t st);
 

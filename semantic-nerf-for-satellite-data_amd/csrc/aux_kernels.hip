@@ -158,6 +158,36 @@ int launch_zero_bytes(void* p, size_t bytes, hipStream_t st) {
 }
 
 // ---- per-ray embedding rows ---------------------------------------------------------------------------------------
+// ---- per-ray sums of a [P][32] fp32 buffer (gradient of the transient codes: bsp_pass.hip, backward step 3) -----------------
+// one wave per ray: lane j takes the samples j, j + 64, ...; the 64 partial sums are folded by shuffles in a fixed tree
+__global__ __launch_bounds__(256) void ray_sum32_kernel(const float* __restrict__ d32, int col0, int N, int S, int tau, float* __restrict__ out) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  for (int j = lane; j < S; j += 64) {
+    const float* q = d32 + ((size_t)n * S + j) * 32 + col0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < tau) acc[c] += q[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c)
+    if (c < tau) {
+      float v = acc[c];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == 0) out[(size_t)n * tau + c] = v;
+    }
+}
+int launch_ray_sum32(const float* d32, int col0, int N, int S, int tau, float* out, hipStream_t st) {
+  if (tau > 16 || col0 < 0 || col0 + tau > 32) { set_error("ray_sum32: tau <= 16 columns inside the 32-wide row"); return SNERF_ERR_BAD_DESC; }
+  hipLaunchKernelGGL(ray_sum32_kernel, dim3((N + 3) / 4), dim3(256), 0, st, d32, col0, N, S, tau, out);
+  SNERF_LAUNCH_CHECK();
+  return SNERF_OK;
+}
+
 __global__ void embedding_rows_kernel(const float* __restrict__ table, int n_embed, int tau, const long long* __restrict__ idx,
                                       int n, float* __restrict__ rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -183,7 +183,6 @@ namespace bsp {
 // x = o + d z, gamma(x) (or raw x) as planes [P][Ep]; the [sun | t | t_s] block as columns [fa_col0, +16) of the [P][FA] tensor
 int launch_encode_bsp(const EncodeArgs& a, char* pe, int* Epe, char* fa, int* Efa, int fa_col0, int pl, hipStream_t st);
 int launch_zero_cols(char* base, size_t pitch, size_t width_bytes, int rows, hipStream_t st);   // width_bytes % 16 == 0
-int launch_ray_sum_bsp(const char* dfa, const int* E, int ld, int col0, int N, int S, int tau, float* out, int pl, hipStream_t st);
 // [rows][32] fp32 -> 256-row partial column sums (+ planes [rows][32] and one exponent per 128 rows when planes != null)
 int launch_colsum32_bsp(const float* in, int rows, float* partial, char* planes, int* E, int pl, hipStream_t st);
 

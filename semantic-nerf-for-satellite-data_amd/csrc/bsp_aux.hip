@@ -1,6 +1,5 @@
 // Producers and converters of block-scaled fp16-plane tensors (bsp.h) that are not GEMM epilogues: positional
-// encoding + per-sample extras, the weight pack, fp32 <-> planes conversion (32-wide head gradients; tests), and the
-// per-ray sum that turns d[feats | extras] into the embedding-row gradient.  All HBM-bound.
+// encoding + per-sample extras, the weight pack, fp32 <-> planes conversion (32-wide head gradients; tests).  All HBM-bound.
 #include "bsp.h"
 #include "aux_kernels.h"
 
@@ -274,47 +273,6 @@ int launch_encode_bsp(const EncodeArgs& a, char* pe, int* Epe, char* fa, int* Ef
   EncodeBsp g{a, pe, Epe, fa, Efa, fa_col0, pl};
   const long long P = (long long)a.N * a.S;
   hipLaunchKernelGGL(encode_bsp_kernel, dim3((unsigned)((P + 127) / 128)), dim3(256), 0, st, g);
-  SNERF_LAUNCH_CHECK();
-  return SNERF_OK;
-}
-
-// ---- d loss / d t[n][c] = sum_s dfa[(n S + s)][col0 + c] from planes -------------------------------------------------
-// One wave per ray: lane j takes the samples j, j + 64, ... (tau <= 16 columns each, in the fixed order of the loop), then the 64
-// partial sums are folded by shuffles in a fixed tree -- deterministic, and 4096 waves instead of N * tau threads walking S rows
-// each (round 3: 70 us per launch at 4096 x 64; the gradient is 32 MB of reads).
-__global__ __launch_bounds__(256) void ray_sum_bsp_kernel(const char* __restrict__ dfa, const int* __restrict__ E, int ld, int col0, int N, int S, int tau,
-                                                          float* __restrict__ out, int pl) {
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (n >= N) return;
-  const int ncb = ncb_of(ld), cb = col0 >> 7;        // the tau columns lie in one exponent block (col0 + tau <= 16 columns of the extras group)
-  float acc[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-  for (int j = lane; j < S; j += 64) {
-    const size_t p = (size_t)n * S + j;
-    const char* q = dfa + p * ld * 2 * pl;
-    const int e = E[(p >> 7) * ncb + cb];
-#pragma unroll
-    for (int c = 0; c < 16; ++c)
-      if (c < tau) {
-        const char* qc = q + g16_off(col0 + c, pl);
-        const float v = (float)*reinterpret_cast<const _Float16*>(qc) + (pl == 2 ? (float)*reinterpret_cast<const _Float16*>(qc + 32) : 0.f);
-        acc[c] += __builtin_amdgcn_ldexpf(v, -e);
-      }
-  }
-#pragma unroll
-  for (int c = 0; c < 16; ++c)
-    if (c < tau) {
-      float v = acc[c];
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == 0) out[(size_t)n * tau + c] = v;
-    }
-}
-
-int launch_ray_sum_bsp(const char* dfa, const int* E, int ld, int col0, int N, int S, int tau, float* out, int pl, hipStream_t st) {
-  if (tau > 16 || ((col0 & 127) + tau > 128)) { set_error("ray_sum: tau <= 16 columns inside one exponent block"); return SNERF_ERR_BAD_DESC; }
-  hipLaunchKernelGGL(ray_sum_bsp_kernel, dim3((N + 3) / 4), dim3(256), 0, st, dfa, E, ld, col0, N, S, tau, out, pl);
   SNERF_LAUNCH_CHECK();
   return SNERF_OK;
 }

@@ -291,12 +291,31 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     RC(dw_reduce(rq, m1, (size_t)p.h1w * p.FA, gp + p.w_h1 + (size_t)r0 * p.FA));
     bsp::KcArgs g;
     g.A = dz1; g.EA = edz1; g.lda = p.h1w; g.Ka = p.h1w; weights(g, p, pk, p.wj_th1, 0, r0);
-    g.I = P; g.J = p.FA; g.K = p.h1w; g.C = dfa; g.EC = edfa; g.ldc = p.FA;
+    // d feats only (J = W): the 16 extras columns would be a third column tile of 256 for 16 useful columns (a third of this
+    // launch: 954 -> ~640 us at 4096 x 64), and nothing needs d sun_d.  The gradient of the transient codes comes from a 32-wide
+    // launch over the head blocks that read them instead (default: the beta block alone, K = H).
+    g.I = P; g.J = W; g.K = p.h1w; g.C = dfa; g.EC = edfa; g.ldc = p.FA;
     cs_ = colsum(g, p.FA);   // columns [0, W) = bias gradient of feats_from_xyz
     RC(launch_kc(g));
     RC(red_add_col(rq.col, cs_, (P + 127) / 128, (size_t)cs_ld(p.FA), W, gp + p.b_fs));
-    if (d_t) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_t, p.N, p.S, p.tau, d_t, p.pl, st));
-    if (d_t_s && p.x_ts >= 0) RC(bsp::launch_ray_sum_bsp(dfa, edfa, p.FA, p.Wf + p.x_ts, p.N, p.S, p.tau, d_t_s, p.pl, st));
+    const bool want_t = d_t != nullptr, want_ts = d_t_s != nullptr && p.x_ts >= 0;
+    if (p.sc) {   // the sun-visibility block reads [feats | sun_d] only: no gradient reaches t / t_s through this pass
+      if (want_t) RC(launch_zero_bytes(d_t, (size_t)p.N * p.tau * sizeof(float), st));
+      if (want_ts) RC(launch_zero_bytes(d_t_s, (size_t)p.N * p.tau * sizeof(float), st));
+    } else if (want_t || want_ts) {
+      // d extras[p][c] = sum_j dz1[p][j] W_h1[j][Wf + c] over the blocks whose first layer reads t or t_s (api.hip: head1)
+      int b_lo = p.blk_beta, b_hi = p.blk_beta;
+      auto use = [&](int blk, bool on) { if (on && blk >= 0) { if (blk < b_lo) b_lo = blk; if (blk > b_hi) b_hi = blk; } };
+      use(p.blk_rgb, p.rgb_t); use(p.blk_sem, p.sem_t || p.sem_ts); use(p.blk_sbeta, true);
+      const int k_lo = b_lo * H, k_n = (b_hi + 1 - b_lo) * H;
+      float* dext = ws.f(p.o_dfin);      // [P][32] fp32: the final-layer gradients that lived here were consumed in step 1
+      bsp::KcArgs x;
+      x.A = dz1; x.EA = edz1; x.lda = p.h1w; x.a_col0 = k_lo; x.Ka = k_n; weights(x, p, pk, p.wj_th1, p.Wf, k_lo);
+      x.I = P; x.J = p.Xp; x.K = k_n; x.Cf = dext;
+      RC(bsp::launch_kc_narrow(x, st));
+      if (want_t) RC(launch_ray_sum32(dext, p.x_t, p.N, p.S, p.tau, d_t, st));
+      if (want_ts) RC(launch_ray_sum32(dext, p.x_ts, p.N, p.S, p.tau, d_t_s, st));
+    }
   }
   char* dz = ws.c(p.o_dza); int* edz = ws.i(p.e_dza);   // dz1 is dead from here on
   {  // 4. feats + sigma: dW for the [W + 32][W] matrix, then dz of the last trunk layer
