@@ -94,6 +94,10 @@ static void plan_bsp(Plan& p) {
   p.o_s2 = planes(p.H); p.e_s2 = etab(p.H); p.o_cs2 = keep_c ? signs(p.H) : 0;
   p.o_s3 = planes(p.H); p.e_s3 = etab(p.H); p.o_cs3 = keep_c ? signs(p.H) : 0;
   p.o_sigo = wtake(Pp * NARROW * 4); p.o_fino = wtake(Pp * NARROW * 4); p.o_suno = wtake(Pp * NARROW * 4);
+  p.nd_sig = p.siren && p.W % 256 == 0 && p.W <= 1024;
+  p.nd_sun = p.siren && p.H % 256 == 0 && p.H <= 1024;
+  if (p.nd_sig) p.o_sigpart = wtake((size_t)4 * (p.W / 256) * Pp * 4);
+  if (p.nd_sun) p.o_sunpart = wtake((size_t)4 * (p.H / 256) * Pp * 4);
   p.o_kcq = wtake((size_t)KCQ_SLOTS * 64);
   p.maxw = p.W > p.FA ? p.W : p.FA;
   if (p.h1w > p.maxw) p.maxw = p.h1w;
@@ -401,7 +405,7 @@ int snerf_test_set_kc_grid(int n) { bsp::kc_set_grid_override(n); return SNERF_O
 // tensors and the output at column c_col0 (exercises the column-offset / exponent-block arithmetic).
 int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, const float* bias, int I, int J, int K, int a_col0,
                       int c_col0, int act, float w0, int aux_mode, const float* Hact, const unsigned* Hsign, float* C,
-                      unsigned* Csign, float* colsum, int narrow, int planes, void* stream) {
+                      unsigned* Csign, float* colsum, const float* nd_w, float* nd_out, int narrow, int planes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (K % 16 || Ka % 16 || Ka <= 0 || Ka > K) { set_error("test_bsp_kc: K, Ka % 16"); return SNERF_ERR_BAD_DESC; }
   if (planes != 1 && planes != 2) { set_error("test_bsp_kc: planes"); return SNERF_ERR_BAD_DESC; }
@@ -442,6 +446,7 @@ int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, c
     g.aux_mode = aux_mode; g.H = ph.as<char>(); g.EH = eh.as<int>(); g.ldh = ldc; g.h_col0 = c_col0; g.Hsign = Hsign;
   }
   g.colsum = colsum; g.ldcs = J;
+  g.nd_w = nd_w; g.nd_out = nd_out; g.nd_stride = (unsigned long long)I;
   DevBuf ctr; TALLOC(ctr, 64);
   SNERF_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, st));
   g.tile_ctr = ctr.as<int>();

@@ -135,6 +135,11 @@ struct KcArgs {
   int dbg = 0;                       // diagnostic builds only (bsp_kc.hip: DIAG); ignored by the product kernels
   int* tile_ctr = nullptr;           // 8 zeroed ints (one 64-byte slot per launch): tiles beyond the first are drawn from them; null: fixed shares
   int pl = 2;                        // planes of EVERY plane tensor of the launch (A, A2, W pack, C, H): 2 (default arithmetic) or 1
+  // ACT_SIN launches of whole 256-column tiles: besides the output, every wave writes for each of its points the dot product of
+  // its 64 output values (fp32, before they are rounded to planes) with nd_w -- the 1-wide projection that follows the layer
+  // (sigma after the trunk, sun visibility after its last hidden layer), as tiles_j * 4 partial sums per point:
+  // nd_out[(tj * 4 + wave) * nd_stride + i].  The consumer adds them in that order (composite.h).
+  const float* nd_w = nullptr; float* nd_out = nullptr; unsigned long long nd_stride = 0;
 };
 // sign word of (32-row block, 64-column group, lane) of a tensor with `ld` columns: bit 8 ps + c <-> row (lane >> 3) + 8 ps,
 // column 8 (lane & 7) + c of that block (the epilogue's own lane mapping, so producer and consumer touch one word per lane)

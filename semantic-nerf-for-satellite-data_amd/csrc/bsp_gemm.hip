@@ -451,6 +451,10 @@ int check_kc(const KcArgs& a, bool narrow) {
     if (a.act != ACT_NONE) return bad("activation and derivative in one epilogue");
   }
   if (a.colsum && (((uintptr_t)a.colsum & 15) || (a.ldcs & 3))) return bad("colsum alignment");
+  if (a.nd_w != nullptr) {
+    if (a.act != ACT_SIN || a.aux_mode != AUX_NONE || !a.nd_out || (a.J & 255) || a.J > 1024 || a.nd_stride < (unsigned long long)a.I || ((uintptr_t)a.nd_w & 15))
+      return bad("folded projection: ACT_SIN forward launch of whole 256-column tiles, J <= 1024, nd_out [tiles_j * 4][nd_stride >= I]");
+  }
   if ((size_t)128 * a.ldc * EB >= 0x7FFFFFFFull) return bad("ldc too large");
   return SNERF_OK;
 }

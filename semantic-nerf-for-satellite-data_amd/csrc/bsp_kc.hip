@@ -39,6 +39,8 @@ constexpr int KC_SMAX = KC_ETAB + 2 * 512;       // 4 floats: the waves' maxima
 constexpr int KC_HSIGN = KC_SMAX + 64;           // four 256-byte sign-word slots per wave
 constexpr int KC_NEXT = KC_HSIGN + 4 * 1024;     // index of the workgroup's next tile (written by wave 0)
 constexpr int KC_LDS = KC_NEXT + 64;
+constexpr int KC_NDW = KC_LDS;                   // NDOT launches: the projection vector nd_w[J], J <= 1024 floats
+constexpr int KC_LDS_ND = KC_NDW + 4096;
 // DIAG (tools/ablate/build_diag.sh only; the product instantiates DIAG = false): KcArgs::dbg removes operand traffic through
 // zero-size descriptors -- 1: A, 2: W (host side), 4: stores, 8: every tile reads the first 128 rows of A (always L2-resident).
 // Timing-only: the results are wrong.
@@ -46,12 +48,15 @@ constexpr int KC_LDS = KC_NEXT + 64;
 // contraction depth -- a "sub-step" below is 64 bytes of every A row = 16 k of two planes (3 products) or 32 k of one plane
 // (1 product per 16 k): same LDS traffic, same request counts, 16 instead of 24 MFMAs per sub-step; a stage (128 bytes per row)
 // is 32 / 64 k deep.
-template <int PL, int ACT, int AUX, bool COLSUM, bool SIGNS, int SINM, bool DIAG = false>
+// NDOT (ACT_SIN only): the 1-wide projection that follows the layer (KcArgs::nd_w) is taken in the epilogue, on the sine values while
+// they are still fp32 registers: one FMA per element, a fold of the two lane halves, one float per point and wave out.  The 32-wide
+// launch that used to re-read the whole activation tensor for it (0.5 GB, HBM-bound) is gone.
+template <int PL, int ACT, int AUX, bool COLSUM, bool SIGNS, int SINM, bool DIAG = false, bool NDOT = false>
 __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   // The arguments are read from the kernarg segment where they are needed (kargs(): a pointer the compiler must take as
   // new at every use site, so that it re-reads instead of keeping ~50 scalars alive across the k-loop and spilling them).
   const kargs_t p = kargs();
-  __shared__ __attribute__((aligned(16))) char lds[KC_LDS];
+  __shared__ __attribute__((aligned(16))) char lds[NDOT ? KC_LDS_ND : KC_LDS];
   float* smax = reinterpret_cast<float*>(lds + KC_SMAX);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -222,6 +227,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   const bool dyn = tile_ctr != nullptr;
   const int n_grp = (gridDim.x & 7) == 0 ? 8 : 1, grp = (int)blockIdx.x & (n_grp - 1);
   const unsigned ctr_off = 4u * (unsigned)grp;
+  if constexpr (NDOT) {   // the projection vector, once per workgroup (published by the first tile's barrier, awaited by its vmcnt(0))
+    const float* ndw = p->nd_w;
+    for (int i = t; i < p->J; i += 256) reinterpret_cast<float*>(lds + KC_NDW)[i] = ndw[i];
+  }
   int vb = blockIdx.x;
   prepare(vb);
   headW();
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       }
     };
     float bj[4][8];
-    if (BIAS) {
+    if (BIAS && !NDOT) {     // (NDOT: re-read per use -- the dot product's registers take the place of the 32 bias registers)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const float4 b0 = *reinterpret_cast<const float4*>(&sbias[wj0 + 16 * gq + 8 * lh]);
@@ -435,9 +444,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     if constexpr (ONEPASS) {
       // ---- sine: one pass.  u = acc * (2^-e w0 / pi) + b w0 / pi (bias row staged in LDS, already scaled)
       const float su = inv_in * e->w0 * INV_PI;
+      const float* snd = reinterpret_cast<const float*>(lds + KC_NDW) + c_j0 + wj0 + 8 * lh;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         unsigned sw = 0u;
+        float nd = 0.f;
         u32x4 ph1[4];
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
@@ -446,9 +457,24 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
           for (int gg = 0; gg < 2; ++gg) {
             const int gq = 2 * nj + gg;
             float v[8];
+            if constexpr (NDOT) {
+              const float4 b0 = *reinterpret_cast<const float4*>(&sbias[wj0 + 16 * gq + 8 * lh]);
+              const float4 b1 = *reinterpret_cast<const float4*>(&sbias[wj0 + 16 * gq + 8 * lh + 4]);
+              v[0] = fmaf(acc[mi][nj][8 * gg + 0], su, b0.x); v[1] = fmaf(acc[mi][nj][8 * gg + 1], su, b0.y);
+              v[2] = fmaf(acc[mi][nj][8 * gg + 2], su, b0.z); v[3] = fmaf(acc[mi][nj][8 * gg + 3], su, b0.w);
+              v[4] = fmaf(acc[mi][nj][8 * gg + 4], su, b1.x); v[5] = fmaf(acc[mi][nj][8 * gg + 5], su, b1.y);
+              v[6] = fmaf(acc[mi][nj][8 * gg + 6], su, b1.z); v[7] = fmaf(acc[mi][nj][8 * gg + 7], su, b1.w);
+            } else {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = fmaf(acc[mi][nj][8 * gg + c], su, bj[gq][c]);
+              for (int c = 0; c < 8; ++c) v[c] = fmaf(acc[mi][nj][8 * gg + c], su, bj[gq][c]);
+            }
             sinpi8<SIGNS, SINM>(v, sw);
+            if constexpr (NDOT) {
+              const float4 w0v = *reinterpret_cast<const float4*>(snd + 16 * gq);
+              const float4 w1v = *reinterpret_cast<const float4*>(snd + 16 * gq + 4);
+              nd = fmaf(v[0], w0v.x, nd); nd = fmaf(v[1], w0v.y, nd); nd = fmaf(v[2], w0v.z, nd); nd = fmaf(v[3], w0v.w, nd);
+              nd = fmaf(v[4], w1v.x, nd); nd = fmaf(v[5], w1v.y, nd); nd = fmaf(v[6], w1v.z, nd); nd = fmaf(v[7], w1v.w, nd);
+            }
             if constexpr (PL == 2) {
               split8(v, 8192.f, phi[gg], plo[gg]);
               strip_put(gg, phi[gg], plo[gg]);
@@ -465,6 +491,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
         if constexpr (PL == 1) {
           strip_flush(mi, 0);
           keep_planes1(ph1);
+        }
+        if constexpr (NDOT) {   // the two lane halves hold the two column halves of every 16-column group of the same point
+          nd += __shfl_xor(nd, 32, 64);
+          if (lh == 0 && 32 * mi + pt < nrows)
+            e->nd_out[(size_t)((c_j0 >> 8) * 4 + wave) * e->nd_stride + (size_t)(c_i0 + 32 * mi + pt)] = nd;
         }
         if (SIGNS && e->Csign != nullptr && wave_cols && 32 * mi < nrows)
           e->Csign[((size_t)((c_i0 >> 5) + mi) * ((e->ldc + 63) >> 6) + ((e->c_col0 + jw) >> 6)) * 64 + el] = sw;
@@ -708,17 +739,21 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   const bool cs = a.colsum != nullptr;
 #define KC_LAUNCH(ACT_, AUX_, CS_, SG_, SM_) do { if (a.pl == 2) hipLaunchKernelGGL((gemm_kc_kernel<2, ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a); \
                                                  else hipLaunchKernelGGL((gemm_kc_kernel<1, ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a); } while (0)
+#define KC_LAUNCH_ND(SG_) do { if (a.pl == 2) hipLaunchKernelGGL((gemm_kc_kernel<2, ACT_SIN, AUX_NONE, false, SG_, SIN_HW, DIAG, true>), grid, block, 0, st, a); \
+                               else hipLaunchKernelGGL((gemm_kc_kernel<1, ACT_SIN, AUX_NONE, false, SG_, SIN_HW, DIAG, true>), grid, block, 0, st, a); } while (0)
   if (a.aux_mode == AUX_SINREC) KC_LAUNCH(ACT_NONE, AUX_SINREC, true, false, SIN_POLY);
   else if (a.aux_mode == AUX_RELU_MASK) KC_LAUNCH(ACT_NONE, AUX_RELU_MASK, true, false, SIN_POLY);
   else if (a.act == ACT_SIN) {
     const bool hw = sin_mode() == SIN_HW;
-    if (a.Csign == nullptr) { if (hw) KC_LAUNCH(ACT_SIN, AUX_NONE, false, false, SIN_HW); else KC_LAUNCH(ACT_SIN, AUX_NONE, false, false, SIN_POLY); }
+    if (a.nd_w != nullptr) { if (a.Csign == nullptr) KC_LAUNCH_ND(false); else KC_LAUNCH_ND(true); }
+    else if (a.Csign == nullptr) { if (hw) KC_LAUNCH(ACT_SIN, AUX_NONE, false, false, SIN_HW); else KC_LAUNCH(ACT_SIN, AUX_NONE, false, false, SIN_POLY); }
     else { if (hw) KC_LAUNCH(ACT_SIN, AUX_NONE, false, true, SIN_HW); else KC_LAUNCH(ACT_SIN, AUX_NONE, false, true, SIN_POLY); }
   }
   else if (a.act == ACT_RELU) KC_LAUNCH(ACT_RELU, AUX_NONE, false, false, SIN_POLY);
   else if (cs) KC_LAUNCH(ACT_NONE, AUX_NONE, true, false, SIN_POLY);
   else KC_LAUNCH(ACT_NONE, AUX_NONE, false, false, SIN_POLY);
 #undef KC_LAUNCH
+#undef KC_LAUNCH_ND
   SNERF_LAUNCH_CHECK();
   prof_hook_end(tok, st);
   return SNERF_OK;

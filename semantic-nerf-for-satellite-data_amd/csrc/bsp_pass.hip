@@ -31,6 +31,12 @@ void weights(bsp::KcArgs& g, const Plan& p, const float* pk, int job, int row0 =
   g.w_row0 = row0; g.w_k0 = k0;
   g.pl = p.pl;
 }
+// sigma / sun-visibility pre-activations of SIREN passes: partial dot products of the producing launches (Plan::nd_sig / nd_sun)
+void narrow_parts(CompArgs& c, const Plan& p, const float* pk, const Ws& ws) {
+  c.part_stride = p.Pp;
+  if (p.nd_sig) { c.sig_part = ws.f(p.o_sigpart); c.n_sig_part = 4 * (p.W / 256); c.sig_bias = pk + p.b_fs + p.W; }
+  if (p.nd_sun) { c.sun_part = ws.f(p.o_sunpart); c.n_sun_part = 4 * (p.H / 256); c.sun_bias = pk + p.b_s4; }
+}
 }  // namespace
 
 int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const SnerfOutputs* out, void* workspace, hipStream_t st) {
@@ -72,10 +78,13 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
     g.C = ws.c(p.o_h[i]); g.EC = ws.i(p.e_h[i]); g.ldc = W;
     g.bias = pk + p.b_tr[i]; g.act = act; g.w0 = (p.siren && i == 0) ? 30.f : 1.f;
     if (p.train && p.siren) g.Csign = ws.u(p.o_c[i]);
+    if (i == p.L - 1 && p.nd_sig) {   // sigma's 1-wide projection rides in this launch's epilogue (bsp_kc.hip: NDOT)
+      g.nd_w = pk + p.w_fs + (size_t)W * W; g.nd_out = ws.f(p.o_sigpart); g.nd_stride = p.Pp;
+    }
     RC(launch_kc(g));
   }
   const char* hl = ws.c(p.o_h[p.L - 1]); const int* ehl = ws.i(p.e_h[p.L - 1]);
-  {  // sigma pre-activation (rs_semantic.py:337) -> 32-wide fp32 buffer, column 0
+  if (!p.nd_sig) {  // sigma pre-activation (rs_semantic.py:337) -> 32-wide fp32 buffer, column 0
     bsp::KcArgs g;
     g.A = hl; g.EA = ehl; g.lda = W; g.Ka = W; weights(g, p, pk, p.wj_sig);
     g.I = P; g.J = NARROW; g.K = W; g.Cf = ws.f(p.o_sigo); g.bias = pk + p.b_fs + W;
@@ -106,9 +115,10 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
     g.A = ws.c(p.o_s2); g.EA = ws.i(p.e_s2); g.lda = H; g.a_col0 = 0; weights(g, p, pk, p.wj_s3);
     g.C = ws.c(p.o_s3); g.EC = ws.i(p.e_s3); g.bias = pk + p.b_s3;
     if (p.train && p.siren) g.Csign = ws.u(p.o_cs3);
+    if (p.nd_sun) { g.nd_w = pk + p.w_s4; g.nd_out = ws.f(p.o_sunpart); g.nd_stride = p.Pp; }   // the sun-visibility output likewise
     RC(launch_kc(g));
   }
-  {  // sun visibility output pre-activation
+  if (!p.nd_sun) {  // sun visibility output pre-activation
     bsp::KcArgs g;
     g.A = ws.c(p.o_s3); g.EA = ws.i(p.e_s3); g.lda = H; g.Ka = H; weights(g, p, pk, p.wj_s4);
     g.I = P; g.J = NARROW; g.K = H; g.Cf = ws.f(p.o_suno); g.bias = pk + p.b_s4;
@@ -124,6 +134,7 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
   CompArgs c;
   c.N = p.N; c.S = p.S; c.H = H; c.C = p.C; c.sc = p.sc; c.sem_sigmoid = p.sem_sigmoid; c.has_sbeta = p.blk_sbeta >= 0;
   c.z = z; c.sigo = ws.f(p.o_sigo); c.fino = ws.f(p.o_fino); c.suno = ws.f(p.o_suno);
+  narrow_parts(c, p, pk, ws);
   c.sun_d = in->sun_d; c.sun_stride = in->sun_stride; c.sky = pk + p.sky;
   c.o_rgb = out->rgb; c.o_depth = out->depth; c.o_weights = out->weights; c.o_transparency = out->transparency;
   c.o_albedo = out->albedo; c.o_sun = out->sun; c.o_sky = out->sky; c.o_beta = out->beta; c.o_sigmas = out->sigmas;
@@ -227,6 +238,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
   CompArgs& c = b.f;
   c.N = p.N; c.S = p.S; c.H = H; c.C = p.C; c.sc = p.sc; c.sem_sigmoid = p.sem_sigmoid; c.has_sbeta = p.blk_sbeta >= 0;
   c.z = ws.f(p.o_z); c.sigo = ws.f(p.o_sigo); c.fino = ws.f(p.o_fino); c.suno = ws.f(p.o_suno);
+  narrow_parts(c, p, pk, ws);
   c.sun_d = in->sun_d; c.sun_stride = in->sun_stride; c.sky = pk + p.sky;
   b.T = ws.f(p.o_T); b.rgbraw = ws.f(p.o_rgbraw);
   b.g_rgb = go->rgb; b.g_depth = go->depth; b.g_weights = go->weights; b.g_transparency = go->transparency;

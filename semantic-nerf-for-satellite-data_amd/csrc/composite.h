@@ -9,6 +9,12 @@ struct CompArgs {
   int sc = 0, sem_sigmoid = 0, has_sbeta = 0;
   const float* z = nullptr;                         // [N][S]
   const float* sigo = nullptr; const float* fino = nullptr; const float* suno = nullptr;  // [P][NARROW] pre-activations
+  // SIREN passes at full width: the sigma / sun-visibility pre-activations arrive as per-wave partial dot products written by
+  // the epilogues of the launches that produce their inputs (bsp_kc.hip: NDOT) -- value(p) = *bias + sum_q part[q * part_stride + p]
+  // in this fixed order; null: read sigo / suno
+  const float* sig_part = nullptr; const float* sig_bias = nullptr; int n_sig_part = 0;
+  const float* sun_part = nullptr; const float* sun_bias = nullptr; int n_sun_part = 0;
+  size_t part_stride = 0;
   const float* sun_d = nullptr; int sun_stride = 3;
   const float* sky = nullptr;                       // packed sky params
   float* o_rgb = nullptr; float* o_depth = nullptr; float* o_weights = nullptr; float* o_transparency = nullptr;

@@ -52,6 +52,15 @@ __device__ __forceinline__ void sky_forward(const float* __restrict__ sky, int H
   for (int c = 0; c < 3; ++c) k[c] = sigmoid_f(wave_sum(part[c]) + b2[c]);
 }
 
+// pre-activation of a 1-wide head (sigma, sun visibility): the 32-wide buffer's column 0, or bias + the partial dot products of the
+// producing launch's epilogue summed in a fixed order (CompArgs::sig_part / sun_part)
+__device__ __forceinline__ float narrow_pre(const float* full, const float* part, const float* bias, int n, size_t stride, size_t p) {
+  if (part == nullptr) return full[p * NARROW];
+  float s = *bias;
+  for (int q = 0; q < n; ++q) s += part[(size_t)q * stride + p];
+  return s;
+}
+
 __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a) {
       const size_t p = (size_t)ray * S + (valid ? j : 0);
       const float zj = a.z[p];
       const float delta = (j >= S - 1) ? 1e10f : (a.z[p + 1] - zj);
-      const float spre = a.sigo[p * NARROW];
+      const float spre = narrow_pre(a.sigo, a.sig_part, a.sig_bias, a.n_sig_part, a.part_stride, p);
       const float sigma = softplus_f(spre);
       const float e = expf(-delta * fmaxf(sigma, 0.f));
       const float alpha = 1.f - e;
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a) {
       const float T = carryT * excl;
       carryT = carryT * __shfl(incl, 63, 64);
       const float w = alpha * T;
-      const float v = sigmoid_f(a.suno[p * NARROW]);
+      const float v = sigmoid_f(narrow_pre(a.suno, a.sun_part, a.sun_bias, a.n_sun_part, a.part_stride, p));
       if (valid) {
         if (a.o_weights) a.o_weights[p] = w;
         if (a.o_transparency) a.o_transparency[p] = T;
@@ -198,14 +207,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompBwdArgs b) {
       const size_t p = (size_t)ray * S + (valid ? j : 0);
       const float zj = a.z[p];
       const float delta = (j >= S - 1) ? 1e10f : (a.z[p + 1] - zj);
-      const float spre = a.sigo[p * NARROW];
+      const float spre = narrow_pre(a.sigo, a.sig_part, a.sig_bias, a.n_sig_part, a.part_stride, p);
       const float sigma = softplus_f(spre);
       const float e = expf(-delta * fmaxf(sigma, 0.f));
       const float alpha = 1.f - e;
       const float tau = (1.f - alpha) + 1e-10f;
       const float T = b.T[p];
       const float w = alpha * T;
-      const float vpre = a.suno[p * NARROW];
+      const float vpre = narrow_pre(a.suno, a.sun_part, a.sun_bias, a.n_sun_part, a.part_stride, p);
       const float v = sigmoid_f(vpre);
 
       float G = b.g_weights ? b.g_weights[p] : 0.f;

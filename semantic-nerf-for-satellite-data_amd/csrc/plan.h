@@ -50,6 +50,10 @@ struct Plan {
   size_t o_h[SNERF_MAX_LAYERS] = {0}, o_c[SNERF_MAX_LAYERS] = {0};
   size_t o_s2 = 0, o_s3 = 0, o_cs2 = 0, o_cs3 = 0;
   size_t o_sigo = 0, o_fino = 0, o_suno = 0;
+  // sigma / sun-visibility pre-activations as partial dot products of the producing SIREN launches' epilogues (bsp_kc.hip: NDOT):
+  // [4 * (W / 256)][Pp] and [4 * (H / 256)][Pp] floats; folded when the producing layer is a SIREN layer of whole 256-column tiles
+  size_t o_sigpart = 0, o_sunpart = 0;
+  bool nd_sig = false, nd_sun = false;
   // backward scratch
   size_t o_dza = 0, o_dzb = 0, o_dsa = 0, o_dsb = 0, o_dsig = 0, o_dfin = 0, o_dsun = 0;
   size_t o_skyslab = 0;

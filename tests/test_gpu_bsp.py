@@ -78,7 +78,7 @@ def kc_grid(request):
 
 
 def _kc(A, W, bias=None, A2=None, act=ACT_NONE, w0=1.0, aux=AUX_NONE, Hact=None, Hsign=None, a_col0=0, c_col0=0,
-        want_sign=False, want_colsum=False, narrow=False, planes=2):
+        want_sign=False, want_colsum=False, narrow=False, planes=2, nd_w=None):
     L, lib = _lib()
     I, Ka = A.shape
     K = Ka + (A2.shape[1] if A2 is not None else 0)
@@ -87,8 +87,11 @@ def _kc(A, W, bias=None, A2=None, act=ACT_NONE, w0=1.0, aux=AUX_NONE, Hact=None,
     ldc = c_col0 + (J + 15) // 16 * 16
     sign = torch.zeros(((I + 127) // 128 * 128 // 32) * ((ldc + 63) // 64) * 64, dtype=torch.int32, device=DEV) if want_sign else None
     cs = torch.zeros(((I + 127) // 128, J), device=DEV) if want_colsum else None
+    nd_out = torch.full((((J + 255) // 256) * 4, I), float("nan"), device=DEV) if nd_w is not None else None
     lib.check(L.snerf_test_bsp_kc(_p(A), _p(A2), Ka, _p(W), _p(bias), I, J, K, a_col0, c_col0, act, w0, aux, _p(Hact), _p(Hsign),
-                                  _p(Cm), _p(sign), _p(cs), int(narrow), planes, _st()), "test_bsp_kc")
+                                  _p(Cm), _p(sign), _p(cs), _p(nd_w), _p(nd_out), int(narrow), planes, _st()), "test_bsp_kc")
+    if nd_w is not None:
+        return Cm, sign, nd_out
     return Cm, sign, cs
 
 
@@ -163,6 +166,35 @@ def test_kc_siren_forward_then_derivative_epilogue(I, J, K, w0, kc_grid):
     assert float(rows[:128].max()) <= tol                 # the quiet rows are as accurate as the loud ones
     want = torch.stack([ref[r:r + 128].sum(0) for r in range(0, I, 128)])
     assert _relerr(cs, want) <= 1e-4
+
+
+@pytest.mark.parametrize("planes", [2, 1])
+@pytest.mark.parametrize("I,J,K,w0,signs", [(300, 512, 512, 1.0, True), (1000, 256, 256, 1.0, False), (257, 1024, 64, 30.0, True)])
+def test_kc_siren_forward_with_folded_projection(I, J, K, w0, signs, planes, kc_grid):
+    """ACT_SIN launches of whole 256-column tiles can take the 1-wide projection that follows the layer (sigma after the trunk, the
+    sun-visibility output) in their epilogue: every wave writes, per point, the dot product of its 64 fp32 sine values with nd_w;
+    the tiles_j * 4 partials summed in order equal h . nd_w (h = the sine values BEFORE they are rounded to planes), and the layer's
+    own output is what it is without the projection."""
+    g = torch.Generator().manual_seed(I + J)
+    X = (torch.rand(I, K, generator=g) * 2 - 1).to(DEV)
+    W = (torch.randn(J, K, generator=g) * (0.3 / K ** 0.5)).to(DEV)
+    b = (torch.randn(J, generator=g) * 0.1).to(DEV)
+    nw = torch.randn(J, generator=g).to(DEV)
+    H0, s0, _ = _kc(X, W, b, act=ACT_SIN, w0=w0, want_sign=signs, planes=planes)
+    H1, s1, parts = _kc(X, W, b, act=ACT_SIN, w0=w0, want_sign=signs, planes=planes, nd_w=nw)
+    assert torch.equal(H0, H1) and (s0 is None or torch.equal(s0, s1))
+    assert parts.shape == ((J // 256) * 4, I) and bool(torch.isfinite(parts).all())
+    got = parts[0].clone()
+    for q in range(1, parts.shape[0]):
+        got += parts[q]
+    z = (X.double() @ W.double().T + b.double()) * w0
+    want = torch.sin(z) @ nw.double()
+    tol = (4e-6 if planes == 2 else 2.0 ** -10 * (1.0 + float(z.abs().max()))) * float(nw.abs().sum())
+    assert float((got.double() - want).abs().max()) <= tol, float((got.double() - want).abs().max())
+    # each partial is one wave's 64 columns
+    hq = torch.sin(z)
+    for q in range(parts.shape[0]):
+        assert float((parts[q].double() - hq[:, 64 * q: 64 * q + 64] @ nw.double()[64 * q: 64 * q + 64]).abs().max()) <= tol
 
 
 def test_kc_relu_forward_and_mask(kc_grid):
