@@ -159,9 +159,11 @@ struct RQ {
   }
 };
 struct DwMat { DwSplit sp; size_t stride; int ldw; float* slab; };
-DwMat dw_begin(const Plan& p, RQ& rq, int rows, int ldw, int cols, bool narrow_rows) {
+// `split_rows`: the rows the split count is chosen for when they differ from the slab's (the [W + 32][W] matrix of feats + sigma:
+// its wide launch covers W rows -- counting the 32 sigma rows as a third row tile gave it 43 splits, 172 workgroups for 256 CUs)
+DwMat dw_begin(const Plan& p, RQ& rq, int rows, int ldw, int cols, bool narrow_rows, int split_rows = 0) {
   DwMat m;
-  m.sp = dw_choose_bsp(p.P, rows, cols, narrow_rows);
+  m.sp = dw_choose_bsp(p.P, split_rows > 0 ? split_rows : rows, cols, narrow_rows);
   m.stride = round_up_sz((size_t)rows * ldw, 64);
   m.ldw = ldw;
   m.slab = rq.take(m.stride * m.sp.ns);
@@ -198,14 +200,14 @@ int narrow_grad(const Plan& p, RQ& rq, const float* dnar, char* planes, int* E, 
 size_t bsp_rq_floats(const Plan& p) {
   size_t n = 0;
   auto take = [&](size_t f) { n += round_up_sz(f, 64); };
-  auto slab = [&](int rows, int ldw, int cols, bool narrow) { take(round_up_sz((size_t)rows * ldw, 64) * dw_choose_bsp(p.P, rows, cols, narrow).ns); };
+  auto slab = [&](int rows, int ldw, int cols, bool narrow, int split_rows = 0) { take(round_up_sz((size_t)rows * ldw, 64) * dw_choose_bsp(p.P, split_rows > 0 ? split_rows : rows, cols, narrow).ns); };
   auto cs = [&](int width) { take((size_t)((p.P + 127) / 128) * ((width + 3) & ~3)); };
   auto nar = [&]() { take((size_t)((p.P + 255) / 256) * NARROW); };
   const int W = p.W, H = p.H;
   if (!p.sc) { nar(); slab(NARROW, p.KF, p.KF, true); cs(p.KF); }
   nar(); slab(NARROW, H, H, true); slab(H, H, H, false); slab(H, H, H, false); cs(H); cs(H); cs(H);
   slab(p.h1w, p.FA, p.FA, false); cs(p.FA);
-  nar(); slab(W + NARROW, W, W, false); cs(W);
+  nar(); slab(W + NARROW, W, W, false, W); cs(W);
   for (int i = p.L - 1; i >= 0; --i) {
     const bool skip = i > 0 && ((p.skip_mask >> i) & 1u);
     if (skip) { slab(W, p.Ep, p.Ep, false); slab(W, W, W, false); }      // [gamma | h] columns: two slab regions (backward_bsp)
@@ -338,7 +340,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
     // of the dX launch are skipped (SURVEY 8(d) counts the sc backward "through sun_v / feats / trunk only").
     const bool sig_live = !p.sc || go->weights != nullptr || go->transparency != nullptr || go->sigmas != nullptr;
     if (sig_live) RC(narrow_grad(p, rq, dsig, ws.c(p.o_pdsig), ws.i(p.e_dsig), gp + p.b_fs + W, st));
-    const DwMat ms = dw_begin(p, rq, W + NARROW, W, W, false);
+    const DwMat ms = dw_begin(p, rq, W + NARROW, W, W, false, W);
     RC(dw_gemm(p, ms, dfa, edfa, p.FA, 0, W, false, hl, ehl, W, 0, W, 0, st));
     if (sig_live) RC(dw_gemm(p, ms, ws.c(p.o_pdsig), ws.i(p.e_dsig), NARROW, 0, NARROW, true, hl, ehl, W, 0, W, (size_t)W * W, st));
     RC(dw_reduce(rq, ms, (size_t)(sig_live ? W + NARROW : W) * W, gp + p.w_fs));
