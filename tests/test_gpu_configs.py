@@ -35,6 +35,9 @@ def _sub(d, idx):
     return {k: v[idx] for k, v in d.items()}
 
 
+REDUCED_MEASURED = []   # what the one-plane mode measured at the configuration sizes (printed with -s)
+
+
 def _subset_parity(cfg, N, n_sub, seed, epoch, monkeypatch=None, mode=None, out_tol=OUT_TOL, loss_rtol=2e-4,
                    grad_tol=GRAD_REL_TOL, exact_z=True, car_prob=0.03, n_images=19):
     """Render N rays on the HIP path; oracle on n_sub of them (stride N // n_sub); outputs, loss terms and the
@@ -64,11 +67,16 @@ def _subset_parity(cfg, N, n_sub, seed, epoch, monkeypatch=None, mode=None, out_
     if out_tol <= 1e-3:
         _compare_outputs(hip_sub, ora, cfg)
     else:   # REDUCED mode: PSNR-style bar, class agreement as a rate
+        worst_out = 0.0
         for k, v in ora.items():
             if k == "semantic_label_coarse":
-                assert float((hip_sub[k].cpu() == v).float().mean()) >= 0.9, "class agreement below 90 %"
+                agree = float((hip_sub[k].cpu() == v).float().mean())
+                assert agree >= 0.98, "class agreement below 98 %"
             else:
-                assert max_abs(hip_sub[k].detach().cpu(), v.detach()) <= out_tol, (k, max_abs(hip_sub[k].detach().cpu(), v.detach()))
+                e = max_abs(hip_sub[k].detach().cpu(), v.detach())
+                worst_out = max(worst_out, e)
+                assert e <= out_tol, (k, e)
+        REDUCED_MEASURED.append({"mode": mode, "N": N, "S": S, "worst_output_abs_err": worst_out, "label_agreement": agree if cfg.model == "semantic" else None})
     # ---- the real loss set on the subset's outputs (all other rays get zero output gradients)
     bsg = {k: v.to(dev) for k, v in bs.items()}
     ld_h = O.training_losses(hip_sub, bsg, cfg, epoch)
@@ -90,6 +98,9 @@ def _subset_parity(cfg, N, n_sub, seed, epoch, monkeypatch=None, mode=None, out_
         assert err <= grad_tol or max_abs(g, r) <= 1e-7 + GRAD_ABS_ESCAPE * (grad_tol / GRAD_REL_TOL) * float(r.abs().max()), (k, err)
     if emb_o.grad is not None:
         assert rel_err(emb_g.grad.cpu(), emb_o.grad) <= grad_tol
+    if mode is not None and REDUCED_MEASURED:
+        REDUCED_MEASURED[-1]["worst_grad_rel_l2"] = worst
+        print("reduced-precision config:", REDUCED_MEASURED[-1])
     return worst, ld_o
 
 
@@ -126,12 +137,13 @@ def test_c3_semantic_car_reg_4096x96_default_arithmetic():
 
 def test_c3_semantic_car_reg_4096x96_bf16(monkeypatch):
     """configs[2] in the arithmetic BASELINE names for it (bf16, the reference's precision = 16): REDUCED precision,
-    judged PSNR-style -- outputs within 2e-2 (PSNR of the rendered colours against the fp32 oracle > 40 dB), loss terms
-    within 1 %, gradients within 5 % relative L2.  These bars are UNPINNED: the reference publishes no reduced-precision
-    numbers and runs no bf16 path here; they are this build's own statement of what "bf16" may cost."""
+    judged PSNR-style -- outputs within 5e-3 of the fp32 oracle (measured 1.3e-3: PSNR of the rendered colours > 57 dB), class
+    agreement >= 98 % (measured 100 %), loss terms within 1 %, gradients within 3 % relative L2 (measured 0.4 %).  These bars are
+    UNPINNED: the reference publishes no reduced-precision numbers and runs no half-precision path here; they are this build's own
+    statement of what the one-plane mode (SNERF_FLAG_F16X1; "bf16" is BASELINE.json's name for it) may cost -- 4x what it measures."""
     cfg = O.OracleCfg(n_samples=96, use_car_reg_loss=True)
-    _subset_parity(cfg, 4096, 256, seed=24, epoch=3, car_prob=0.1, monkeypatch=monkeypatch, mode="bf16", out_tol=2e-2,
-                   loss_rtol=1e-2, grad_tol=5e-2)
+    _subset_parity(cfg, 4096, 256, seed=24, epoch=3, car_prob=0.1, monkeypatch=monkeypatch, mode="bf16", out_tol=5e-3,
+                   loss_rtol=1e-2, grad_tol=3e-2)
 
 
 def test_c4_semantic_2048x128():
@@ -141,12 +153,12 @@ def test_c4_semantic_2048x128():
 
 
 def test_c5_semantic_4096x128_bf16(monkeypatch):
-    """configs[4] per-GPU training shape (32768 x 128 over 8 GPUs, bf16): 524 k points per pass; REDUCED-precision bar as
-    in test_c3_*_bf16 (UNPINNED, see there).  (The configuration's full-frame inference half:
+    """configs[4] per-GPU training shape (32768 x 128 over 8 GPUs, bf16): 524 k points per pass; REDUCED-precision bars as
+    in test_c3_*_bf16 (UNPINNED, see there; measured here: outputs 9.7e-4, gradients 0.7 %).  (The configuration's full-frame inference half:
     test_full_frame_inference_chunk_beyond_4gib.)"""
     cfg = O.OracleCfg(n_samples=128)
-    _subset_parity(cfg, 4096, 128, seed=26, epoch=2, monkeypatch=monkeypatch, mode="bf16", out_tol=2e-2, loss_rtol=1e-2,
-                   grad_tol=5e-2)
+    _subset_parity(cfg, 4096, 128, seed=26, epoch=2, monkeypatch=monkeypatch, mode="bf16", out_tol=5e-3, loss_rtol=1e-2,
+                   grad_tol=3e-2)
 
 
 def test_c5_semantic_4096x128_default_arithmetic():
