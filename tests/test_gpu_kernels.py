@@ -178,6 +178,13 @@ def test_full_width_forward_backward(name):
     for k in z.files:
         if k.startswith("out_") and k != "out_semantic_label_coarse":
             assert max_abs(hip[k[4:]].detach().cpu(), z[k]) <= OUT_TOL, (k, max_abs(hip[k[4:]].detach().cpu(), z[k]))
+    # the inference-mode pass (no stored activations, no sign words: other instantiations of the same kernels, incl. the folded
+    # sigma / sun projections of full-width SIREN passes) gives the training-mode results bit for bit
+    with torch.no_grad():
+        inf = _hip_render(cfg, gp, emb_g, b, dev)
+    inf.pop("_z_vals")
+    for k, v in hip.items():
+        assert torch.equal(inf[k], v.detach()), k
     bg = {k: v.to(dev) for k, v in b.items()}
     ld = O.training_losses(hip, bg, cfg, meta["epoch"])
     for k in ld:
