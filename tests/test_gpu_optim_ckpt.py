@@ -121,6 +121,36 @@ def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
     assert only and all(k.startswith("fc_net") for k in only)
 
 
+def test_pass_workspaces_are_leased_not_reallocated():
+    """Round 3's driver-timed bench lost 240 ms to a hipMalloc of a 10 GB pass workspace INSIDE the timed steps: torch's caching
+    allocator had carved a result tensor out of the idle block while the previous step's results were still referenced.  Workspaces are
+    now leased from ops' pool (device, stream, size): steps that hold the previous step's results must neither allocate device
+    memory nor grow the reserved bytes, and main / sc pass get the same two tensors back every step."""
+    from snerf_amd import ops
+    ops.release_workspaces()
+    loop = _loop()
+    held = []
+    for s in range(3):                      # warm-up: the pool fills, torch's small blocks settle
+        torch.manual_seed(s)
+        held = [loop.step(s)]
+    torch.cuda.synchronize()
+    idle = {k: [t.data_ptr() for t in v] for k, v in ops._WS_FREE.items()}
+    assert len(idle) >= 2 and all(len(v) == 1 for v in idle.values()), idle          # one idle workspace per (stream, size): main, sc
+    m0 = torch.cuda.memory_stats(DEV)
+    for s in range(3, 9):
+        torch.manual_seed(s)
+        held.append(loop.step(s))           # results of EVERY step stay referenced while the next one allocates
+    torch.cuda.synchronize()
+    m1 = torch.cuda.memory_stats(DEV)
+    assert {k: [t.data_ptr() for t in v] for k, v in ops._WS_FREE.items()} == idle    # the same tensors came back
+    big = max(k[2] for k in idle)
+    assert m1["num_alloc_retries"] == m0["num_alloc_retries"] and m1["num_ooms"] == m0["num_ooms"]
+    # held result tensors may make torch take small blocks; nothing of a workspace's size is ever requested again
+    assert m1["reserved_bytes.all.current"] - m0["reserved_bytes.all.current"] < big, (m0["reserved_bytes.all.current"], m1["reserved_bytes.all.current"], big)
+    ops.release_workspaces()
+    assert not ops._WS_FREE
+
+
 def test_trainloop_gradients_live_in_the_flat_bucket():
     loop = _loop()
     torch.manual_seed(0)
