@@ -30,6 +30,13 @@ __device__ __forceinline__ void dma16_asm(srd_words srd, unsigned lds_byte_addr,
                : "=&s"(keep)
                : "s"(lds_byte_addr), "v"(voff), "s"(srd), "s"(soff));
 }
+// the same request with the non-temporal cache policy: data that is read exactly once (the stored activations of a derivative epilogue)
+__device__ __forceinline__ void dma16_asm_nt(srd_words srd, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 2\n\tbuffer_load_dwordx4 %2, %3, %4 offen nt lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_byte_addr), "v"(voff), "s"(srd), "s"(soff));
+}
 // one dword per lane (256 B per wave) by the same route
 __device__ __forceinline__ void dma4_asm(srd_words srd, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
   unsigned keep;

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(TI == 256 ? 512 : 256, 2) void gemm_dw_kernel(const
       const bool ok = col < p.J && (i0 + wi0 + rl) < p.I;    // J % 4 == 0
       const float4 v = *reinterpret_cast<const float4*>(&strip[(rrow + 4 * ps) * 68 + c4]);
       const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-      __builtin_amdgcn_raw_buffer_store_b128(d, srdC, ok ? ((unsigned)rl * (unsigned)p.ldc + (unsigned)c4) * 4u : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(d, srdC, ok ? ((unsigned)rl * (unsigned)p.ldc + (unsigned)c4) * 4u : OOB, 0, 2);
     }
   }
 }

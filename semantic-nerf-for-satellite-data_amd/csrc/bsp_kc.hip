@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) {
         const u32x4 d = *reinterpret_cast<const u32x4*>(strip + sr_off + 1024 * ps);
-        __builtin_amdgcn_raw_buffer_store_b128(d, srdC, voC[nj], (unsigned)(4 * mi + ps) * stepC8, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(d, srdC, voC[nj], (unsigned)(4 * mi + ps) * stepC8, 2);
       }
     };
     float bj[4][8];
@@ -531,13 +531,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
             const int c = (el & 7) ^ ((q >> 1) & 7);                // chunk of the half-row this lane fetches
             const bool ok = jw + 32 * nj + 16 * (c >> 2) < e->J;
             const unsigned vo = ok ? (unsigned)q * (unsigned)e->ldh * 4u + (unsigned)((jw >> 4) + 2 * nj) * 64u + 16u * (unsigned)c : OOBH;
-            dma16_asm(srdH, hbuf[hb & 1] + (unsigned)(pc * 1024), vo, (unsigned)(32 * mi) * (unsigned)e->ldh * 4u);
+            dma16_asm_nt(srdH, hbuf[hb & 1] + (unsigned)(pc * 1024), vo, (unsigned)(32 * mi) * (unsigned)e->ldh * 4u);
           } else {
             const int q = 16 * pc + hq;
             const int c = (el & 3) ^ ((q >> 2) & 3);                // eight columns each
             const bool ok = jw + 32 * nj + 8 * c < e->J;
             const unsigned vo = ok ? (unsigned)q * (unsigned)e->ldh * 2u + (unsigned)(jw + 32 * nj) * 2u + 16u * (unsigned)c : OOBH;
-            dma16_asm(srdH, hbuf[hb & 1] + (unsigned)(pc * 1024), vo, (unsigned)(32 * mi) * (unsigned)e->ldh * 2u);
+            dma16_asm_nt(srdH, hbuf[hb & 1] + (unsigned)(pc * 1024), vo, (unsigned)(32 * mi) * (unsigned)e->ldh * 2u);
           }
         }
       };
