@@ -284,7 +284,9 @@ int snerf_test_set_kc_grid(int n_workgroups);   /* persistent grid of the K-cont
 int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int col0, float* dst, int* exps_out, int planes, void* stream);
 int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, const float* bias, int I, int J, int K, int a_col0,
                       int c_col0, int act, float w0, int aux_mode, const float* Hact, const unsigned* Hsign, float* C,
-                      unsigned* Csign, float* colsum, const float* nd_w, float* nd_out, int narrow, int planes, void* stream);   /* nd_w [J] / nd_out [ceil(J/256)*4][I]: the folded 1-wide projection of ACT_SIN launches */
+                      unsigned* Csign, float* colsum, const float* nd_w, float* nd_out, const int* nd_rows, int narrow, int planes, void* stream);
+/* nd_w [J] / nd_out [ceil(J/256)*4][I]: the folded 1-wide projection of ACT_SIN launches; with nd_rows (HOST array, one count <= 5 per
+ * 256-column tile): nd_w [sum nd_rows][J], nd_out [ceil(J/256)*4*5][I] -- the folded final head layers */
 int snerf_test_bsp_dw(const float* A, int lda_src, const float* B, int ldb_src, int P, int I, int J, int a_col0, int b_col0,
                       int k_split, int narrow_i, float* C, int planes, void* stream);
 

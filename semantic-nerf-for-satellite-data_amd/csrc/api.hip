@@ -93,11 +93,14 @@ static void plan_bsp(Plan& p) {
   p.o_h1 = planes(p.h1w); p.e_h1 = etab(p.h1w); p.o_c1 = keep_c ? signs(p.h1w) : 0;
   p.o_s2 = planes(p.H); p.e_s2 = etab(p.H); p.o_cs2 = keep_c ? signs(p.H) : 0;
   p.o_s3 = planes(p.H); p.e_s3 = etab(p.H); p.o_cs3 = keep_c ? signs(p.H) : 0;
-  p.o_sigo = wtake(Pp * NARROW * 4); p.o_fino = wtake(Pp * NARROW * 4); p.o_suno = wtake(Pp * NARROW * 4);
+  // the narrow projections: folded into the producing SIREN launch's epilogue where its width is whole 256-column tiles (partial sums
+  // per wave, summed by the composite), otherwise a 32-wide fp32 buffer written by a launch of their own
   p.nd_sig = p.siren && p.W % 256 == 0 && p.W <= 1024;
   p.nd_sun = p.siren && p.H % 256 == 0 && p.H <= 1024;
-  if (p.nd_sig) p.o_sigpart = wtake((size_t)4 * (p.W / 256) * Pp * 4);
-  if (p.nd_sun) p.o_sunpart = wtake((size_t)4 * (p.H / 256) * Pp * 4);
+  p.nd_fin = !p.sc && p.siren && p.H == 256 && p.C <= ND_FIN;   // one 256-column tile per head block, at most ND_FIN outputs per block
+  if (p.nd_sig) p.o_sigpart = wtake((size_t)4 * (p.W / 256) * Pp * 4); else p.o_sigo = wtake(Pp * NARROW * 4);
+  if (p.nd_sun) p.o_sunpart = wtake((size_t)4 * (p.H / 256) * Pp * 4); else p.o_suno = wtake(Pp * NARROW * 4);
+  if (p.nd_fin) p.o_finpart = wtake((size_t)4 * (p.KF / 256) * ND_FIN * Pp * 4); else if (!p.sc) p.o_fino = wtake(Pp * NARROW * 4);
   p.o_kcq = wtake((size_t)KCQ_SLOTS * 64);
   p.maxw = p.W > p.FA ? p.W : p.FA;
   if (p.h1w > p.maxw) p.maxw = p.h1w;
@@ -405,7 +408,7 @@ int snerf_test_set_kc_grid(int n) { bsp::kc_set_grid_override(n); return SNERF_O
 // tensors and the output at column c_col0 (exercises the column-offset / exponent-block arithmetic).
 int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, const float* bias, int I, int J, int K, int a_col0,
                       int c_col0, int act, float w0, int aux_mode, const float* Hact, const unsigned* Hsign, float* C,
-                      unsigned* Csign, float* colsum, const float* nd_w, float* nd_out, int narrow, int planes, void* stream) {
+                      unsigned* Csign, float* colsum, const float* nd_w, float* nd_out, const int* nd_rows, int narrow, int planes, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (K % 16 || Ka % 16 || Ka <= 0 || Ka > K) { set_error("test_bsp_kc: K, Ka % 16"); return SNERF_ERR_BAD_DESC; }
   if (planes != 1 && planes != 2) { set_error("test_bsp_kc: planes"); return SNERF_ERR_BAD_DESC; }
@@ -447,6 +450,10 @@ int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, c
   }
   g.colsum = colsum; g.ldcs = J;
   g.nd_w = nd_w; g.nd_out = nd_out; g.nd_stride = (unsigned long long)I;
+  if (nd_w && nd_rows) {   // several projections per column tile: nd_w [sum rows][J], tile tj's rows follow tile tj - 1's
+    g.nd_omax = ND_FIN; g.nd_ldw = J;
+    for (int tj = 0, r = 0; tj < (J + 255) / 256 && tj < 8; ++tj) { g.nd_rows[tj] = nd_rows[tj]; g.nd_row0[tj] = r; r += nd_rows[tj]; }
+  }
   DevBuf ctr; TALLOC(ctr, 64);
   SNERF_HIP_CHECK(hipMemsetAsync(ctr.p, 0, 64, st));
   g.tile_ctr = ctr.as<int>();

@@ -139,7 +139,12 @@ struct KcArgs {
   // its 64 output values (fp32, before they are rounded to planes) with nd_w -- the 1-wide projection that follows the layer
   // (sigma after the trunk, sun visibility after its last hidden layer), as tiles_j * 4 partial sums per point:
   // nd_out[(tj * 4 + wave) * nd_stride + i].  The consumer adds them in that order (composite.h).
+  // General form (nd_omax = 5: the final head layers): column tile tj takes nd_rows[tj] (<= nd_omax) projections, rows nd_row0[tj] .. of
+  // the matrix nd_w (leading dimension nd_ldw), restricted to the tile's 256 columns; nd_out[((tj * 4 + wave) * nd_omax + o) * nd_stride + i].
+  // The 1-wide form is nd_omax = 1, nd_rows = 1, nd_row0 = 0 for every tile (launch_kc fills that in when nd_omax == 0).
   const float* nd_w = nullptr; float* nd_out = nullptr; unsigned long long nd_stride = 0;
+  int nd_omax = 0, nd_ldw = 0;
+  int nd_rows[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nd_row0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nd_woff[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // nd_woff: filled by launch_kc
 };
 // sign word of (32-row block, 64-column group, lane) of a tensor with `ld` columns: bit 8 ps + c <-> row (lane >> 3) + 8 ps,
 // column 8 (lane & 7) + c of that block (the epilogue's own lane mapping, so producer and consumer touch one word per lane)

@@ -9,6 +9,19 @@ namespace bsp {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
+// HAZARD (measured on gfx950, round 4; tools/check_lds_hazard.py finds the pattern in the assembly, tests/test_build_cpu.py runs it):
+// a VALU instruction issued right behind a buffer_store_dwordx4 may overwrite the store's DATA registers before the store has
+// fetched them -- dword 0 of lanes 25/27/29/31 (+32) then carried the VALU result (a row index) in ~1.5 % of the rows, different
+// from run to run.  LLVM's hazard recognizer inserts the wait state only for stores with an immediate soffset (the documented
+// case); the plane stores use an SGPR soffset and got none.  Call this behind every wide store with its data: the
+// value stays live across two wait states, so no later write can be allocated into those registers any earlier.
+// (-DKC_NO_STORE_GUARD: tools/ablate/build_noguard.sh, the reproducer of the corruption -- never the product build)
+__device__ __forceinline__ void store_data_guard(const u32x4& d) {
+#ifndef KC_NO_STORE_GUARD
+  asm volatile("s_nop 1" ::"v"(d));
+#endif
+}
+
 __device__ __forceinline__ void dma16(srd_t srd, char* lds_dst, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
 }

@@ -410,6 +410,7 @@ __global__ __launch_bounds__(TI == 256 ? 512 : 256, 2) void gemm_dw_kernel(const
       const float4 v = *reinterpret_cast<const float4*>(&strip[(rrow + 4 * ps) * 68 + c4]);
       const u32x4 d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
       __builtin_amdgcn_raw_buffer_store_b128(d, srdC, ok ? ((unsigned)rl * (unsigned)p.ldc + (unsigned)c4) * 4u : OOB, 0, 2);
+      store_data_guard(d);
     }
   }
 }
@@ -452,8 +453,8 @@ int check_kc(const KcArgs& a, bool narrow) {
   }
   if (a.colsum && (((uintptr_t)a.colsum & 15) || (a.ldcs & 3))) return bad("colsum alignment");
   if (a.nd_w != nullptr) {
-    if (a.act != ACT_SIN || a.aux_mode != AUX_NONE || !a.nd_out || (a.J & 255) || a.J > 1024 || a.nd_stride < (unsigned long long)a.I || ((uintptr_t)a.nd_w & 15))
-      return bad("folded projection: ACT_SIN forward launch of whole 256-column tiles, J <= 1024, nd_out [tiles_j * 4][nd_stride >= I]");
+    if (a.act != ACT_SIN || a.aux_mode != AUX_NONE || !a.nd_out || (a.J & 255) || a.J > 2048 || a.nd_stride < (unsigned long long)a.I || ((uintptr_t)a.nd_w & 15))
+      return bad("folded projection: ACT_SIN forward launch of whole 256-column tiles, J <= 2048, nd_out [tiles_j * 4 * nd_omax][nd_stride >= I]");
   }
   if ((size_t)128 * a.ldc * EB >= 0x7FFFFFFFull) return bad("ldc too large");
   return SNERF_OK;

@@ -36,11 +36,12 @@ constexpr int KC_XREG = KC_RINGB;                // epilogue: 4 KiB per wave (pl
 constexpr int KC_BIAS = KC_XREG + 4 * 4096;      // 2 x 256 floats: the tile's bias (times w0 / pi for the sine epilogue), by tile parity
 constexpr int KC_ETAB = KC_BIAS + 2 * 1024;      // 2 x 128 ints: exponent of every 16-deep k-step, by tile parity
 constexpr int KC_SMAX = KC_ETAB + 2 * 512;       // 4 floats: the waves' maxima
-constexpr int KC_HSIGN = KC_SMAX + 64;           // four 256-byte sign-word slots per wave
-constexpr int KC_NEXT = KC_HSIGN + 4 * 1024;     // index of the workgroup's next tile (written by wave 0)
-constexpr int KC_LDS = KC_NEXT + 64;
-constexpr int KC_NDW = KC_LDS;                   // NDOT launches: the projection vector nd_w[J], J <= 1024 floats
-constexpr int KC_LDS_ND = KC_NDW + 4096;
+constexpr int KC_NEXT = KC_SMAX + 64;            // index of the workgroup's next tile (written by wave 0)
+constexpr int KC_HSIGN = KC_NEXT + 64;           // four 256-byte sign-word slots per wave (derivative epilogues)
+constexpr int KC_LDS = KC_HSIGN + 4 * 1024;
+constexpr int KC_NDW = KC_HSIGN;                 // NDOT launches (forward only: no sign-word slots): the projection vectors, <= KC_NDW_FLOATS floats
+constexpr int KC_NDW_FLOATS = 2560;              // 10 KiB: e.g. (3 + 5 + 1 + 1) rows of 256 columns (the final head layers), or one row of <= 1024
+constexpr int KC_LDS_ND = KC_NDW + 4 * KC_NDW_FLOATS;
 // DIAG (tools/ablate/build_diag.sh only; the product instantiates DIAG = false): KcArgs::dbg removes operand traffic through
 // zero-size descriptors -- 1: A, 2: W (host side), 4: stores, 8: every tile reads the first 128 rows of A (always L2-resident).
 // Timing-only: the results are wrong.
@@ -51,12 +52,14 @@ constexpr int KC_LDS_ND = KC_NDW + 4096;
 // NDOT (ACT_SIN only): the 1-wide projection that follows the layer (KcArgs::nd_w) is taken in the epilogue, on the sine values while
 // they are still fp32 registers: one FMA per element, a fold of the two lane halves, one float per point and wave out.  The 32-wide
 // launch that used to re-read the whole activation tensor for it (0.5 GB, HBM-bound) is gone.
-template <int PL, int ACT, int AUX, bool COLSUM, bool SIGNS, int SINM, bool DIAG = false, bool NDOT = false>
+// NDOT = 5: up to five projections per column tile (the final layers of the rgb / semantic / beta heads: each head block is one column tile
+// of the fused first head layer and owns 3 / C / 1 output rows of the block-diagonal final matrix): nd_rows / nd_row0 per column tile.
+template <int PL, int ACT, int AUX, bool COLSUM, bool SIGNS, int SINM, bool DIAG = false, int NDOT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   // The arguments are read from the kernarg segment where they are needed (kargs(): a pointer the compiler must take as
   // new at every use site, so that it re-reads instead of keeping ~50 scalars alive across the k-loop and spilling them).
   const kargs_t p = kargs();
-  __shared__ __attribute__((aligned(16))) char lds[NDOT ? KC_LDS_ND : KC_LDS];
+  __shared__ __attribute__((aligned(16))) char lds[NDOT > 0 ? KC_LDS_ND : KC_LDS];
   float* smax = reinterpret_cast<float*>(lds + KC_SMAX);
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -227,9 +230,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   const bool dyn = tile_ctr != nullptr;
   const int n_grp = (gridDim.x & 7) == 0 ? 8 : 1, grp = (int)blockIdx.x & (n_grp - 1);
   const unsigned ctr_off = 4u * (unsigned)grp;
-  if constexpr (NDOT) {   // the projection vector, once per workgroup (published by the first tile's barrier, awaited by its vmcnt(0))
+  if constexpr (NDOT > 0) {   // the projection vectors, once per workgroup (published by the first tile's barrier, awaited by its vmcnt(0)):
+    // column tile tj owns rows nd_row0[tj] .. + nd_rows[tj] of nd_w (leading dimension nd_ldw), its 256 columns of them, at nd_woff[tj]
     const float* ndw = p->nd_w;
-    for (int i = t; i < p->J; i += 256) reinterpret_cast<float*>(lds + KC_NDW)[i] = ndw[i];
+    float* snd0 = reinterpret_cast<float*>(lds + KC_NDW);
+    for (int tjx = 0; tjx < tiles_j; ++tjx) {
+      const int nr = p->nd_rows[tjx], r0 = p->nd_row0[tjx], wo = p->nd_woff[tjx], ldw = p->nd_ldw;
+      for (int o = 0; o < nr; ++o) snd0[wo + 256 * o + t] = (256 * tjx + t < p->J) ? ndw[(size_t)(r0 + o) * ldw + 256 * tjx + t] : 0.f;
+    }
   }
   int vb = blockIdx.x;
   prepare(vb);
@@ -428,10 +436,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       for (int ps = 0; ps < 4; ++ps) {
         const u32x4 d = *reinterpret_cast<const u32x4*>(strip + sr_off + 1024 * ps);
         __builtin_amdgcn_raw_buffer_store_b128(d, srdC, voC[nj], (unsigned)(4 * mi + ps) * stepC8, 2);
+        store_data_guard(d);
       }
     };
     float bj[4][8];
-    if (BIAS && !NDOT) {     // (NDOT: re-read per use -- the dot product's registers take the place of the 32 bias registers)
+    if (BIAS && NDOT == 0) {     // (NDOT: re-read per use -- the dot product's registers take the place of the 32 bias registers)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const float4 b0 = *reinterpret_cast<const float4*>(&sbias[wj0 + 16 * gq + 8 * lh]);
@@ -444,11 +453,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     if constexpr (ONEPASS) {
       // ---- sine: one pass.  u = acc * (2^-e w0 / pi) + b w0 / pi (bias row staged in LDS, already scaled)
       const float su = inv_in * e->w0 * INV_PI;
-      const float* snd = reinterpret_cast<const float*>(lds + KC_NDW) + c_j0 + wj0 + 8 * lh;
+      const int c_tj = c_j0 >> 8;
+      const int nd_n = NDOT > 0 ? e->nd_rows[c_tj] : 0;      // projections of this column tile (uniform)
+      const float* snd = reinterpret_cast<const float*>(lds + KC_NDW) + (NDOT > 0 ? e->nd_woff[c_tj] : 0) + wj0 + 8 * lh;
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         unsigned sw = 0u;
-        float nd = 0.f;
+        float nd[NDOT > 0 ? NDOT : 1];
+#pragma unroll
+        for (int o = 0; o < (NDOT > 0 ? NDOT : 1); ++o) nd[o] = 0.f;
         u32x4 ph1[4];
 #pragma unroll
         for (int nj = 0; nj < 2; ++nj) {
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
           for (int gg = 0; gg < 2; ++gg) {
             const int gq = 2 * nj + gg;
             float v[8];
-            if constexpr (NDOT) {
+            if constexpr (NDOT > 0) {
               const float4 b0 = *reinterpret_cast<const float4*>(&sbias[wj0 + 16 * gq + 8 * lh]);
               const float4 b1 = *reinterpret_cast<const float4*>(&sbias[wj0 + 16 * gq + 8 * lh + 4]);
               v[0] = fmaf(acc[mi][nj][8 * gg + 0], su, b0.x); v[1] = fmaf(acc[mi][nj][8 * gg + 1], su, b0.y);
@@ -469,11 +482,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
               for (int c = 0; c < 8; ++c) v[c] = fmaf(acc[mi][nj][8 * gg + c], su, bj[gq][c]);
             }
             sinpi8<SIGNS, SINM>(v, sw);
-            if constexpr (NDOT) {
-              const float4 w0v = *reinterpret_cast<const float4*>(snd + 16 * gq);
-              const float4 w1v = *reinterpret_cast<const float4*>(snd + 16 * gq + 4);
-              nd = fmaf(v[0], w0v.x, nd); nd = fmaf(v[1], w0v.y, nd); nd = fmaf(v[2], w0v.z, nd); nd = fmaf(v[3], w0v.w, nd);
-              nd = fmaf(v[4], w1v.x, nd); nd = fmaf(v[5], w1v.y, nd); nd = fmaf(v[6], w1v.z, nd); nd = fmaf(v[7], w1v.w, nd);
+            if constexpr (NDOT > 0) {
+#pragma unroll
+              for (int o = 0; o < NDOT; ++o)
+                if (NDOT == 1 || o < nd_n) {
+                  const float4 w0v = *reinterpret_cast<const float4*>(snd + 256 * o + 16 * gq);
+                  const float4 w1v = *reinterpret_cast<const float4*>(snd + 256 * o + 16 * gq + 4);
+                  nd[o] = fmaf(v[0], w0v.x, nd[o]); nd[o] = fmaf(v[1], w0v.y, nd[o]); nd[o] = fmaf(v[2], w0v.z, nd[o]); nd[o] = fmaf(v[3], w0v.w, nd[o]);
+                  nd[o] = fmaf(v[4], w1v.x, nd[o]); nd[o] = fmaf(v[5], w1v.y, nd[o]); nd[o] = fmaf(v[6], w1v.z, nd[o]); nd[o] = fmaf(v[7], w1v.w, nd[o]);
+                }
             }
             if constexpr (PL == 2) {
               split8(v, 8192.f, phi[gg], plo[gg]);
@@ -492,10 +509,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
           strip_flush(mi, 0);
           keep_planes1(ph1);
         }
-        if constexpr (NDOT) {   // the two lane halves hold the two column halves of every 16-column group of the same point
-          nd += __shfl_xor(nd, 32, 64);
-          if (lh == 0 && 32 * mi + pt < nrows)
-            e->nd_out[(size_t)((c_j0 >> 8) * 4 + wave) * e->nd_stride + (size_t)(c_i0 + 32 * mi + pt)] = nd;
+        if constexpr (NDOT > 0) {   // the two lane halves hold the two column halves of every 16-column group of the same point
+#pragma unroll
+          for (int o = 0; o < NDOT; ++o)
+            if (NDOT == 1 || o < nd_n) {
+              const float tot = nd[o] + __shfl_xor(nd[o], 32, 64);
+              if (lh == 0 && 32 * mi + pt < nrows)
+                e->nd_out[(size_t)((c_tj * 4 + wave) * NDOT + o) * e->nd_stride + (size_t)(c_i0 + 32 * mi + pt)] = tot;
+            }
         }
         if (SIGNS && e->Csign != nullptr && wave_cols && 32 * mi < nrows)
           e->Csign[((size_t)((c_i0 >> 5) + mi) * ((e->ldc + 63) >> 6) + ((e->c_col0 + jw) >> 6)) * 64 + el] = sw;
@@ -725,6 +746,13 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   if (cs_bias_check(a)) return SNERF_ERR_BAD_DESC;
   a.tiles_i = (a.I + 127) / 128;
   a.tiles_j = (a.J + 255) / 256;
+  if (a.nd_w != nullptr) {   // the projections' LDS layout: column tile tj's rows at nd_woff[tj], 256 floats each
+    if (a.nd_omax == 0) { a.nd_omax = 1; a.nd_ldw = 0; for (int tj = 0; tj < 8; ++tj) { a.nd_rows[tj] = tj < a.tiles_j ? 1 : 0; a.nd_row0[tj] = 0; } }
+    int off = 0;
+    for (int tj = 0; tj < a.tiles_j && tj < 8; ++tj) { a.nd_woff[tj] = off; off += 256 * a.nd_rows[tj]; }
+    if (a.tiles_j > 8 || off > KC_NDW_FLOATS || (a.nd_omax != 1 && a.nd_omax != 5)) { set_error("bsp gemm: folded projections beyond the LDS table"); return SNERF_ERR_BAD_DESC; }
+    for (int tj = 0; tj < a.tiles_j; ++tj) if (a.nd_rows[tj] > a.nd_omax) { set_error("bsp gemm: nd_rows > nd_omax"); return SNERF_ERR_BAD_DESC; }
+  }
 #ifdef KC_DIAG_BUILD
   constexpr bool DIAG = true;
   static const int dbg = [] { const char* e = getenv("SNERF_KC_DBG"); return e ? atoi(e) : 0; }();
@@ -739,13 +767,14 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   const bool cs = a.colsum != nullptr;
 #define KC_LAUNCH(ACT_, AUX_, CS_, SG_, SM_) do { if (a.pl == 2) hipLaunchKernelGGL((gemm_kc_kernel<2, ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a); \
                                                  else hipLaunchKernelGGL((gemm_kc_kernel<1, ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a); } while (0)
-#define KC_LAUNCH_ND(SG_) do { if (a.pl == 2) hipLaunchKernelGGL((gemm_kc_kernel<2, ACT_SIN, AUX_NONE, false, SG_, SIN_HW, DIAG, true>), grid, block, 0, st, a); \
-                               else hipLaunchKernelGGL((gemm_kc_kernel<1, ACT_SIN, AUX_NONE, false, SG_, SIN_HW, DIAG, true>), grid, block, 0, st, a); } while (0)
+#define KC_LAUNCH_ND(SG_, ND_) do { if (a.pl == 2) hipLaunchKernelGGL((gemm_kc_kernel<2, ACT_SIN, AUX_NONE, false, SG_, SIN_HW, DIAG, ND_>), grid, block, 0, st, a); \
+                                    else hipLaunchKernelGGL((gemm_kc_kernel<1, ACT_SIN, AUX_NONE, false, SG_, SIN_HW, DIAG, ND_>), grid, block, 0, st, a); } while (0)
   if (a.aux_mode == AUX_SINREC) KC_LAUNCH(ACT_NONE, AUX_SINREC, true, false, SIN_POLY);
   else if (a.aux_mode == AUX_RELU_MASK) KC_LAUNCH(ACT_NONE, AUX_RELU_MASK, true, false, SIN_POLY);
   else if (a.act == ACT_SIN) {
     const bool hw = sin_mode() == SIN_HW;
-    if (a.nd_w != nullptr) { if (a.Csign == nullptr) KC_LAUNCH_ND(false); else KC_LAUNCH_ND(true); }
+    if (a.nd_w != nullptr && a.nd_omax == 1) { if (a.Csign == nullptr) KC_LAUNCH_ND(false, 1); else KC_LAUNCH_ND(true, 1); }
+    else if (a.nd_w != nullptr) { if (a.Csign == nullptr) KC_LAUNCH_ND(false, 5); else KC_LAUNCH_ND(true, 5); }
     else if (a.Csign == nullptr) { if (hw) KC_LAUNCH(ACT_SIN, AUX_NONE, false, false, SIN_HW); else KC_LAUNCH(ACT_SIN, AUX_NONE, false, false, SIN_POLY); }
     else { if (hw) KC_LAUNCH(ACT_SIN, AUX_NONE, false, true, SIN_HW); else KC_LAUNCH(ACT_SIN, AUX_NONE, false, true, SIN_POLY); }
   }

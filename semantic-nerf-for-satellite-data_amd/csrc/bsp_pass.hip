@@ -36,6 +36,10 @@ void narrow_parts(CompArgs& c, const Plan& p, const float* pk, const Ws& ws) {
   c.part_stride = p.Pp;
   if (p.nd_sig) { c.sig_part = ws.f(p.o_sigpart); c.n_sig_part = 4 * (p.W / 256); c.sig_bias = pk + p.b_fs + p.W; }
   if (p.nd_sun) { c.sun_part = ws.f(p.o_sunpart); c.n_sun_part = 4 * (p.H / 256); c.sun_bias = pk + p.b_s4; }
+  if (p.nd_fin) {
+    c.fin_part = ws.f(p.o_finpart); c.fin_bias = pk + p.b_fin;
+    c.fin_blk[0] = p.blk_rgb; c.fin_blk[1] = p.blk_sem < 0 ? 0 : p.blk_sem; c.fin_blk[2] = p.blk_beta; c.fin_blk[3] = p.blk_sbeta < 0 ? 0 : p.blk_sbeta;
+  }
 }
 }  // namespace
 
@@ -103,6 +107,11 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
     g.I = P; g.J = p.h1w; g.K = p.FA; g.C = ws.c(p.o_h1); g.EC = ws.i(p.e_h1); g.ldc = p.h1w;
     g.bias = pk + p.b_h1 + r0; g.act = act; g.w0 = 1.f;
     if (p.train && p.siren) g.Csign = ws.u(p.o_c1);
+    if (p.nd_fin) {   // the heads' final layers (block-diagonal [32][KF]: block b's rows read only block b's 256 columns) in this launch's epilogue
+      g.nd_w = pk + p.w_fin; g.nd_ldw = p.KF; g.nd_omax = ND_FIN; g.nd_out = ws.f(p.o_finpart); g.nd_stride = p.Pp;
+      auto blk = [&](int b, int col, int n) { if (b >= 0) { g.nd_rows[b] = n; g.nd_row0[b] = col; } };
+      blk(p.blk_rgb, Plan::col_rgb, 3); blk(p.blk_sem, Plan::col_sem, p.C); blk(p.blk_beta, Plan::col_beta, 1); blk(p.blk_sbeta, Plan::col_sbeta, 1);
+    }
     RC(launch_kc(g));
   }
   const int sun_col = p.sc ? 0 : p.sun_col;
@@ -124,7 +133,7 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
     g.I = P; g.J = NARROW; g.K = H; g.Cf = ws.f(p.o_suno); g.bias = pk + p.b_s4;
     RC(bsp::launch_kc_narrow(g, st));
   }
-  if (!p.sc) {  // last layer of rgb / beta / beta_s / semantic heads: block-diagonal [32][KF]
+  if (!p.sc && !p.nd_fin) {  // last layer of rgb / beta / beta_s / semantic heads: block-diagonal [32][KF]
     bsp::KcArgs g;
     g.A = ws.c(p.o_h1); g.EA = ws.i(p.e_h1); g.lda = p.h1w; g.Ka = p.KF; weights(g, p, pk, p.wj_fin);
     g.I = P; g.J = NARROW; g.K = p.KF; g.Cf = ws.f(p.o_fino); g.bias = pk + p.b_fin;

@@ -15,6 +15,9 @@ struct CompArgs {
   const float* sig_part = nullptr; const float* sig_bias = nullptr; int n_sig_part = 0;
   const float* sun_part = nullptr; const float* sun_bias = nullptr; int n_sun_part = 0;
   size_t part_stride = 0;
+  // the final head layers likewise (NDOT = 5): column c of `fino` = fin_bias[c] + sum_{w < 4} fin_part[((blk * 4 + w) * ND_FIN + o) * part_stride + p],
+  // blk = the head's block (fin_blk: rgb, semantic, beta, beta_s), o = the column's index inside its head
+  const float* fin_part = nullptr; const float* fin_bias = nullptr; int fin_blk[4] = {0, 0, 0, 0};
   const float* sun_d = nullptr; int sun_stride = 3;
   const float* sky = nullptr;                       // packed sky params
   float* o_rgb = nullptr; float* o_depth = nullptr; float* o_weights = nullptr; float* o_transparency = nullptr;

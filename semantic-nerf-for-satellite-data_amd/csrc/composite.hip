@@ -61,6 +61,16 @@ __device__ __forceinline__ float narrow_pre(const float* full, const float* part
   return s;
 }
 
+// pre-activation `o` of head `h` (0 rgb, 1 semantic, 2 beta, 3 beta_s; `col` = its column in the 32-wide buffer)
+__device__ __forceinline__ float fin_pre(const CompArgs& a, size_t p, int col, int h, int o) {
+  if (a.fin_part == nullptr) return a.fino[p * NARROW + col];
+  const float* q = a.fin_part + (size_t)(a.fin_blk[h] * 4 * ND_FIN + o) * a.part_stride + p;
+  float s = a.fin_bias[col];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) s += q[(size_t)(w * ND_FIN) * a.part_stride];
+  return s;
+}
+
 __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -103,27 +113,26 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a) {
         if (a.save_T) a.save_T[p] = T;
       }
       if (a.sc) continue;
-      const float* fin = a.fino + p * NARROW;
       float al[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        al[c] = sigmoid_f(fin[Plan::col_rgb + c]) * 1.002f - 0.001f;
+        al[c] = sigmoid_f(fin_pre(a, p, Plan::col_rgb + c, 0, c)) * 1.002f - 0.001f;
         const float irr = v + (1.f - v) * k[c];
         if (valid) acc_rgb[c] += (w * al[c]) * irr;
       }
-      const float beta = softplus_f(fin[Plan::col_beta]);
+      const float beta = softplus_f(fin_pre(a, p, Plan::col_beta, 2, 0));
       if (valid) {
         acc_depth += w * zj;
         if (a.o_sigmas) a.o_sigmas[p] = sigma;
         if (a.o_beta) a.o_beta[p] = beta;
         if (a.o_albedo) { a.o_albedo[p * 3 + 0] = al[0]; a.o_albedo[p * 3 + 1] = al[1]; a.o_albedo[p * 3 + 2] = al[2]; }
         if (a.o_sky) { a.o_sky[p * 3 + 0] = k[0]; a.o_sky[p * 3 + 1] = k[1]; a.o_sky[p * 3 + 2] = k[2]; }
-        if (a.o_beta_s && a.has_sbeta) a.o_beta_s[p] = softplus_f(fin[Plan::col_sbeta]);
+        if (a.o_beta_s && a.has_sbeta) a.o_beta_s[p] = softplus_f(fin_pre(a, p, Plan::col_sbeta, 3, 0));
       }
 #pragma unroll
       for (int c = 0; c < MAX_CLASSES; ++c) {
         if (c < C) {
-          const float pre = fin[Plan::col_sem + c];
+          const float pre = fin_pre(a, p, Plan::col_sem + c, 1, c);
           const float q = a.sem_sigmoid ? sigmoid_f(pre) : pre;
           if (valid) acc_log[c] += w * q;
         }
@@ -223,11 +232,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompBwdArgs b) {
 #pragma unroll
       for (int c = 0; c < MAX_CLASSES; ++c) d_qpre[c] = 0.f;
       if (!a.sc) {
-        const float* fin = a.fino + p * NARROW;
         G += gdepth * zj;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float sa = sigmoid_f(fin[Plan::col_rgb + c]);
+          const float sa = sigmoid_f(fin_pre(a, p, Plan::col_rgb + c, 0, c));
           const float al = sa * 1.002f - 0.001f;
           const float irr = v + (1.f - v) * k[c];
           G += grgb[c] * (al * irr);
@@ -237,14 +245,14 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompBwdArgs b) {
           g_v += g_irr * (1.f - k[c]);
           if (valid) gk[c] += g_irr * (1.f - v) + (b.g_sky ? b.g_sky[p * 3 + c] : 0.f);
         }
-        const float bpre = fin[Plan::col_beta];
+        const float bpre = fin_pre(a, p, Plan::col_beta, 2, 0);
         d_bpre = (b.g_beta ? b.g_beta[p] : 0.f) * softplus_grad_f(bpre);
-        if (a.has_sbeta) d_sbpre = (b.g_beta_s ? b.g_beta_s[p] : 0.f) * softplus_grad_f(fin[Plan::col_sbeta]);
+        if (a.has_sbeta) d_sbpre = (b.g_beta_s ? b.g_beta_s[p] : 0.f) * softplus_grad_f(fin_pre(a, p, Plan::col_sbeta, 3, 0));
 #pragma unroll
         for (int c = 0; c < MAX_CLASSES; ++c) {
           if (c < C) {
             const float gl = b.g_logits ? b.g_logits[(size_t)ray * C + c] : 0.f;
-            const float pre = fin[Plan::col_sem + c];
+            const float pre = fin_pre(a, p, Plan::col_sem + c, 1, c);
             const float q = a.sem_sigmoid ? sigmoid_f(pre) : pre;
             G += gl * q;
             d_qpre[c] = a.sem_sigmoid ? (gl * w) * q * (1.f - q) : gl * w;

@@ -9,6 +9,7 @@ namespace snerf {
 
 constexpr int NARROW = 32;   // padded width of the 1..(5+C)-wide head outputs
 constexpr int MAX_CLASSES = 16;
+constexpr int ND_FIN = 5;       // projections per column tile of a folded final-layer launch (bsp_kc.hip: NDOT = 5)
 constexpr int MAX_SKY_UNITS = 8;  // feat_last <= 512 (units per lane in the composite kernels)
 
 struct Plan {
@@ -52,8 +53,9 @@ struct Plan {
   size_t o_sigo = 0, o_fino = 0, o_suno = 0;
   // sigma / sun-visibility pre-activations as partial dot products of the producing SIREN launches' epilogues (bsp_kc.hip: NDOT):
   // [4 * (W / 256)][Pp] and [4 * (H / 256)][Pp] floats; folded when the producing layer is a SIREN layer of whole 256-column tiles
-  size_t o_sigpart = 0, o_sunpart = 0;
+  size_t o_sigpart = 0, o_sunpart = 0, o_finpart = 0;
   bool nd_sig = false, nd_sun = false;
+  bool nd_fin = false;   // the final layers of the rgb / semantic / beta heads ride in the fused first head layer's epilogue (H = 256: one column tile per head)
   // backward scratch
   size_t o_dza = 0, o_dzb = 0, o_dsa = 0, o_dsb = 0, o_dsig = 0, o_dfin = 0, o_dsun = 0;
   size_t o_skyslab = 0;

@@ -78,7 +78,7 @@ def kc_grid(request):
 
 
 def _kc(A, W, bias=None, A2=None, act=ACT_NONE, w0=1.0, aux=AUX_NONE, Hact=None, Hsign=None, a_col0=0, c_col0=0,
-        want_sign=False, want_colsum=False, narrow=False, planes=2, nd_w=None):
+        want_sign=False, want_colsum=False, narrow=False, planes=2, nd_w=None, nd_rows=None):
     L, lib = _lib()
     I, Ka = A.shape
     K = Ka + (A2.shape[1] if A2 is not None else 0)
@@ -87,9 +87,10 @@ def _kc(A, W, bias=None, A2=None, act=ACT_NONE, w0=1.0, aux=AUX_NONE, Hact=None,
     ldc = c_col0 + (J + 15) // 16 * 16
     sign = torch.zeros(((I + 127) // 128 * 128 // 32) * ((ldc + 63) // 64) * 64, dtype=torch.int32, device=DEV) if want_sign else None
     cs = torch.zeros(((I + 127) // 128, J), device=DEV) if want_colsum else None
-    nd_out = torch.full((((J + 255) // 256) * 4, I), float("nan"), device=DEV) if nd_w is not None else None
+    nd_out = torch.full((((J + 255) // 256) * 4 * (5 if nd_rows else 1), I), float("nan"), device=DEV) if nd_w is not None else None
+    rows_c = (C.c_int * len(nd_rows))(*nd_rows) if nd_rows else None
     lib.check(L.snerf_test_bsp_kc(_p(A), _p(A2), Ka, _p(W), _p(bias), I, J, K, a_col0, c_col0, act, w0, aux, _p(Hact), _p(Hsign),
-                                  _p(Cm), _p(sign), _p(cs), _p(nd_w), _p(nd_out), int(narrow), planes, _st()), "test_bsp_kc")
+                                  _p(Cm), _p(sign), _p(cs), _p(nd_w), _p(nd_out), rows_c, int(narrow), planes, _st()), "test_bsp_kc")
     if nd_w is not None:
         return Cm, sign, nd_out
     return Cm, sign, cs
@@ -195,6 +196,36 @@ def test_kc_siren_forward_with_folded_projection(I, J, K, w0, signs, planes, kc_
     hq = torch.sin(z)
     for q in range(parts.shape[0]):
         assert float((parts[q].double() - hq[:, 64 * q: 64 * q + 64] @ nw.double()[64 * q: 64 * q + 64]).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("planes", [2, 1])
+@pytest.mark.parametrize("I,rows,signs", [(300, (3, 5, 1, 0), True), (1000, (3, 1, 1, 0, 0), False), (257, (0, 5, 5), True)])
+def test_kc_siren_forward_with_folded_final_layers(I, rows, signs, planes, kc_grid):
+    """The general form of the folded projection: column tile tj of the launch takes rows[tj] <= 5 projections of ITS 256 columns (the
+    fused first head layer: one tile per head, whose final layer is rows[tj] x 256 -- 3 colours, C classes, 1 beta; the sun block's
+    tile takes none).  Partials land at nd_out[(tj * 4 + wave) * 5 + o]; slots beyond rows[tj] are never written."""
+    J, K = 256 * len(rows), 528
+    g = torch.Generator().manual_seed(I + J)
+    X = (torch.rand(I, K, generator=g) * 2 - 1).to(DEV)
+    W = (torch.randn(J, K, generator=g) * (0.3 / K ** 0.5)).to(DEV)
+    b = (torch.randn(J, generator=g) * 0.1).to(DEV)
+    nw = torch.randn(sum(rows), J, generator=g).to(DEV)
+    H0, s0, _ = _kc(X, W, b, act=ACT_SIN, want_sign=signs, planes=planes)
+    H1, s1, parts = _kc(X, W, b, act=ACT_SIN, want_sign=signs, planes=planes, nd_w=nw, nd_rows=rows)
+    assert torch.equal(H0, H1) and (s0 is None or torch.equal(s0, s1))
+    parts = parts.view(len(rows), 4, 5, I)
+    hq = torch.sin(X.double() @ W.double().T + b.double())
+    r0 = 0
+    for tj, n in enumerate(rows):
+        assert bool(torch.isnan(parts[tj, :, n:]).all()), "a slot beyond the tile's projections was written"
+        for o in range(n):
+            wrow = nw[r0 + o].double()
+            tol = (4e-6 if planes == 2 else 2.0 ** -10 * 2.0) * float(wrow[256 * tj: 256 * tj + 256].abs().sum())
+            for w in range(4):
+                c0 = 256 * tj + 64 * w
+                want = hq[:, c0: c0 + 64] @ wrow[c0: c0 + 64]
+                assert float((parts[tj, w, o].double() - want).abs().max()) <= tol, (tj, w, o)
+        r0 += n
 
 
 def test_kc_relu_forward_and_mask(kc_grid):

@@ -18,7 +18,7 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 outs = []
 for r in range(3):
     H = torch.empty(P, J, device=dev)
-    _lib.check(L.snerf_test_bsp_kc(p(X), None, K, p(Wm), p(b), P, J, K, 0, 0, act, 1.0, 0, None, None, p(H), None, None, None, None, 0, 2, st), "fwd")
+    _lib.check(L.snerf_test_bsp_kc(p(X), None, K, p(Wm), p(b), P, J, K, 0, 0, act, 1.0, 0, None, None, p(H), None, None, None, None, None, 0, 2, st), "fwd")
     outs.append(H)
 torch.cuda.synchronize()
 print("run0 == run1:", torch.equal(outs[0], outs[1]), " run0 == run2:", torch.equal(outs[0], outs[2]))

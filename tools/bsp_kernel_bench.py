@@ -36,19 +36,19 @@ cs = torch.zeros(P // 32, W, device=dev)
 nw = torch.randn(W, generator=g).to(dev)
 ndo = torch.empty(8, P, device=dev)
 for _ in range(reps if which in ("all", "kc", "fwd", "fwdnd") else 1):   # forward SIREN layer (always once: the dX launches need H and the sign words)
-    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), p(b), P, W, W, 0, 0, 1, 1.0, 0, None, None, p(H), p(sign), None, p(nw) if which == "fwdnd" else None, p(ndo) if which == "fwdnd" else None, 0, planes, st), "fwd")
+    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), p(b), P, W, W, 0, 0, 1, 1.0, 0, None, None, p(H), p(sign), None, p(nw) if which == "fwdnd" else None, p(ndo) if which == "fwdnd" else None, None, 0, planes, st), "fwd")
 for _ in range(reps if which in ("plain",) else 0):   # forward layer without activation
-    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), p(b), P, W, W, 0, 0, 0, 1.0, 0, None, None, p(H), None, None, None, None, 0, planes, st), "plain")
+    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(Wm), p(b), P, W, W, 0, 0, 0, 1.0, 0, None, None, p(H), None, None, None, None, None, 0, planes, st), "plain")
 G = torch.randn(P, W, generator=g).to(dev) * 1e-3
 D = torch.empty(P, W, device=dev)
 for _ in range(reps if which in ("all", "kc", "dx") else 0):   # dX with the derivative epilogue + bias-gradient column sums
-    _lib.check(L.snerf_test_bsp_kc(p(G), None, W, p(Wm), None, P, W, W, 0, 0, 0, 1.0, 3, p(H), p(sign), p(D), None, p(cs), None, None, 0, planes, st), "dx")
+    _lib.check(L.snerf_test_bsp_kc(p(G), None, W, p(Wm), None, P, W, W, 0, 0, 0, 1.0, 3, p(H), p(sign), p(D), None, p(cs), None, None, None, 0, planes, st), "dx")
 Cw = torch.empty(W, W, device=dev)
 for _ in range(reps if which in ("all", "dw") else 0):   # dW, 64 splits
     _lib.check(L.snerf_test_bsp_dw(p(G), W, p(X), W, P, W, W, 0, 0, 4096, 0, p(Cw), planes, st), "dw")
 S32 = torch.empty(P, 32, device=dev)
 W32 = (torch.randn(32, W, generator=g) * 0.05).to(dev)
 for _ in range(reps if which in ("all", "narrow") else 0):   # 32-wide head
-    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(W32), None, P, 32, W, 0, 0, 0, 1.0, 0, None, None, p(S32), None, None, None, None, 1, planes, st), "narrow")
+    _lib.check(L.snerf_test_bsp_kc(p(X), None, W, p(W32), None, P, 32, W, 0, 0, 0, 1.0, 0, None, None, p(S32), None, None, None, None, None, 1, planes, st), "narrow")
 torch.cuda.synchronize()
 print("ok")
