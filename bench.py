@@ -335,20 +335,28 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    step = 0
-    for _ in range(args.warmup):
-        out = loop.step(step)      # held like in the timed loop: the warm-up must have the timed region's memory profile
-        step += 1
-    barrier()
     # per-step marks on the compute stream (no host sync inside the timed region) and the host's wall clock at the same points:
     # the line carries BOTH series in issue order, so a stall can be placed (which step) and attributed (device or host).
     import gc
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     host_t = [0.0] * (args.steps + 1)
-    gc.collect()
-    gc.freeze()          # nothing allocated before this point is ever scanned again
     gc_was = gc.isenabled()
-    gc.disable()         # no collector pause inside the timed region (re-enabled right after it)
+    step = 0
+    for w in range(args.warmup):
+        if w == max(0, args.warmup - 2):
+            # The harness's own housekeeping goes HERE, behind a synchronize of its own and in front of the last warm-up steps -- not
+            # between the warm-up and the timed region: gc.collect() takes tens of ms with torch loaded, the idle GPU drops its
+            # clocks meanwhile and the first timed step then ran 3.3 ms long while they ramped (tools/first_step_probe.py: 29.5 ms
+            # after 50 ms of idling, 26.4 ms after a bare synchronize).  A training run never idles the device like that.
+            torch.cuda.synchronize()
+            gc.collect()
+            gc.freeze()          # nothing allocated before this point is ever scanned again
+            gc.disable()         # no collector pause inside the timed region (re-enabled right after it)
+        out = loop.step(step)      # held like in the timed loop: the warm-up must have the timed region's memory profile
+        step += 1
+    if args.warmup == 0:
+        gc.collect(); gc.freeze(); gc.disable()
+    barrier()
     mem0 = torch.cuda.memory_stats(device)
     t0 = time.perf_counter()
     marks[0].record()
@@ -382,7 +390,7 @@ def main():
         "host_max_step_ms": max(host_step_ms), "host_max_step_index": max(range(args.steps), key=lambda i: host_step_ms[i]),
         "allocator_delta": {k: int(mem1.get(k, 0) - mem0.get(k, 0)) for k in
                             ("num_alloc_retries", "num_device_alloc", "num_device_free", "num_ooms", "reserved_bytes.all.current")},
-        "gc": "frozen + disabled over the timed region",
+        "gc": "collected + frozen + disabled in front of the last two warm-up steps (the device does not idle between warm-up and timed region)",
     }
     # Roofline phase (after the timed region, so the headline number carries no event overhead): the same steps with
     # the main and solar-correction passes serialised -- in the timed region their kernels overlap on two HIP streams,
