@@ -18,8 +18,21 @@ def _host_linspace(n: int):
     return torch.linspace(0, 1, n)
 
 
+_Z_STEPS_DEV: dict = {}
+
+
 def z_steps_on(device, n: int) -> torch.Tensor:
-    return _host_linspace(n).to(device)
+    """The host's linspace on `device`, copied ONCE per (device, n).  (Copied per call it was the step's one blocking call: a
+    host-to-device copy from pageable memory returns when the stream has reached it, i.e. the host waited a whole step behind
+    the device here every step and the device then idled ~0.13 ms while the host caught up -- tools/host_timeline.py.)"""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (device.type, device.index, n)
+    t = _Z_STEPS_DEV.get(key)
+    if t is None:
+        t = _Z_STEPS_DEV[key] = _host_linspace(n).to(device)
+    return t
 
 
 class BaseRenderer:
