@@ -201,20 +201,26 @@ __global__ void embedding_rows_kernel(const float* __restrict__ table, int n_emb
 // sums are added in thread order -- a fixed summation order for any ray permutation of the same batch order
 __global__ __launch_bounds__(256) void embedding_backward_kernel(const long long* __restrict__ idx, const float* __restrict__ d_rows,
                                                                  int n, int tau, float* __restrict__ grad) {
-  __shared__ float part[256];
+  constexpr int TMAX = 16;                 // t_dim <= 16 (api.hip: make_plan; launch_embedding_backward checks)
+  __shared__ float part[TMAX][257];
   const long long v = blockIdx.x;
-  for (int c = 0; c < tau; ++c) {
-    float s = 0.f;
-    for (int r = threadIdx.x; r < n; r += 256)
-      if (idx[r] == v) s += d_rows[(size_t)r * tau + c];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float a = 0.f;
-      for (int t = 0; t < 256; ++t) a += part[t];
-      grad[(size_t)v * tau + c] += a;
+  float s[TMAX];
+#pragma unroll
+  for (int c = 0; c < TMAX; ++c) s[c] = 0.f;
+  for (int r = threadIdx.x; r < n; r += 256)   // the index list is read once for all columns
+    if (idx[r] == v) {
+#pragma unroll
+      for (int c = 0; c < TMAX; ++c)
+        if (c < tau) s[c] += d_rows[(size_t)r * tau + c];
     }
-    __syncthreads();
+#pragma unroll
+  for (int c = 0; c < TMAX; ++c)
+    if (c < tau) part[c][threadIdx.x] = s[c];
+  __syncthreads();
+  if ((int)threadIdx.x < tau) {            // one thread per column adds the 256 partials in thread order
+    float a = 0.f;
+    for (int t = 0; t < 256; ++t) a += part[threadIdx.x][t];
+    grad[(size_t)v * tau + threadIdx.x] += a;
   }
 }
 int launch_embedding_rows(const float* table, int n_embed, int tau, const long long* idx, int n, float* rows, hipStream_t st) {
@@ -223,6 +229,7 @@ int launch_embedding_rows(const float* table, int n_embed, int tau, const long l
   return 0;
 }
 int launch_embedding_backward(const long long* idx, const float* d_rows, int n, int tau, int n_embed, float* grad, hipStream_t st) {
+  if (tau < 1 || tau > 16) { set_error("embedding_backward: t_dim must be in 1..16"); return SNERF_ERR_BAD_DESC; }
   hipLaunchKernelGGL(embedding_backward_kernel, dim3(n_embed), dim3(256), 0, st, idx, d_rows, n, tau, grad);
   SNERF_LAUNCH_CHECK();
   return 0;

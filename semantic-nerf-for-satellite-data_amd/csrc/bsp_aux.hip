@@ -86,11 +86,13 @@ int launch_from_planes(const char* src, const int* E, int ld, int col0, int rows
 __global__ __launch_bounds__(256) void wmax_kernel(WPackChunk tb, const float* __restrict__ master, unsigned* __restrict__ maxbits) {
   const WPackJob j = tb.j[blockIdx.y];
   if (j.transposed) return;            // its matrix is covered by the non-transposed job with the same exponent slot
-  const size_t n = (size_t)j.m_rows * j.m_cols;
   float m = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const size_t r = i / j.m_cols;
-    m = fmaxf(m, fabsf(master[j.src_off + r * j.src_ld + (i - r * j.m_cols)]));
+  // a wave per row (rows strided over the grid's waves), lanes along the row: coalesced, no index division per element (the
+  // element-strided loop this replaces spent 43 us on 2.8 M parameters, most of it in 64-bit divisions)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * 4 + wave; r < j.m_rows; r += gridDim.x * 4) {
+    const float* row = master + j.src_off + (size_t)r * j.src_ld;
+    for (int c = lane; c < j.m_cols; c += 64) m = fmaxf(m, fabsf(row[c]));
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));

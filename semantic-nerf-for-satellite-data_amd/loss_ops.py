@@ -85,7 +85,8 @@ class _FusedLoss(torch.autograd.Function):
             keep.append(v)
             li.labels = v.data_ptr()
         if aux.get("mask") is not None:
-            v = aux["mask"].reshape(-1).to(torch.uint8).contiguous()
+            v = aux["mask"].reshape(-1)
+            v = (v.view(torch.uint8) if v.dtype == torch.bool else v.to(torch.uint8)).contiguous()   # bool -> uint8: a view, no launch
             keep.append(v)
             li.mask = v.data_ptr()
         nws = L.snerf_loss_workspace_bytes(C.byref(cfg))
@@ -118,10 +119,13 @@ class _FusedLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
-        out = [None, None, None]
-        for g in ctx.grads:
-            out.append(None if g is None else g * g_total)
-        return tuple(out)
+        grads, ctx.grads = ctx.grads, None
+        if grads is None:
+            raise RuntimeError("snerf_amd: second backward through one fused loss (its gradient buffers were scaled in place by the first)")
+        live = [g for g in grads if g is not None]
+        if live:
+            torch._foreach_mul_(live, g_total)       # one launch for all of them (the buffers are this node's own)
+        return (None, None, None) + tuple(grads)
 
 
 def fused_loss(spec: LossSpec, results: dict, aux: dict, typ: str = "coarse", sync: bool = True):

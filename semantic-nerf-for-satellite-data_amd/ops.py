@@ -431,12 +431,15 @@ class _RenderPass(torch.autograd.Function):
         keys = output_keys(spec, sc_pass)
         outs = {k: _empty(_OUT_SHAPES[k](N, S, spec.n_classes), dtype=torch.float32, device=dev) for k in keys}
         label = _empty((N,), dtype=torch.int64, device=dev) if (spec.n_classes > 0 and not sc_pass) else None
-        z_out = _empty((N, S), dtype=torch.float32, device=dev)
         so = _lib.SnerfOutputs()
         for k, v in outs.items():
             setattr(so, k, v.data_ptr())
         so.semantic_label = label.data_ptr() if label is not None else None
-        so.z_vals = z_out.data_ptr()
+        if pin.z_vals is not None and pin.z_vals.is_contiguous() and pin.z_vals.dtype == torch.float32:
+            z_out = pin.z_vals.detach()          # depths given: they ARE the result (no copy-out launch)
+        else:
+            z_out = _empty((N, S), dtype=torch.float32, device=dev)
+            so.z_vals = z_out.data_ptr()
         _check_dev(t, "t")
         tc = t.contiguous()
         tsc = t_s.contiguous() if t_s is not None else None
