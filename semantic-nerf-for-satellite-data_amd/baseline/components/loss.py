@@ -5,7 +5,7 @@ loss_dict keys; the arithmetic (forward values and gradients) runs in the fused 
 import torch
 
 from ... import _lib
-from ...loss_ops import LossSpec, fused_loss
+from ...loss_ops import LossSpec, fused_loss, run_plans
 
 _T = {k: i for i, k in enumerate(_lib.LOSS_TERMS)}
 
@@ -26,11 +26,13 @@ class SNerfLoss(torch.nn.Module):
         self.lambda_sc = lambda_sc
         self.solar_correction_enabled = solar_correction_enabled
 
-    def forward(self, inputs, targets):
+    def plan(self, inputs, targets):
+        """(LossSpec, aux, loss_dict keys) of this module's call: loss_ops.run_plans merges it with other modules' plans"""
         sc = self.lambda_sc > 0 and self.solar_correction_enabled
-        spec = LossSpec(color_mode=1, has_sc=sc, sc_lambda=float(self.lambda_sc))
-        loss, terms = fused_loss(spec, inputs, {"gt_rgb": targets})
-        return loss, _pick(terms, ["coarse_color"] + _sc_keys(sc))
+        return LossSpec(color_mode=1, has_sc=sc, sc_lambda=float(self.lambda_sc)), {"gt_rgb": targets}, ["coarse_color"] + _sc_keys(sc)
+
+    def forward(self, inputs, targets):
+        return run_plans([self.plan(inputs, targets)], inputs)
 
 
 class SatNerfLoss(torch.nn.Module):
@@ -41,11 +43,13 @@ class SatNerfLoss(torch.nn.Module):
         self.lambda_sc = lambda_sc
         self.solar_correction_enabled = solar_correction_enabled
 
-    def forward(self, inputs, targets):
+    def plan(self, inputs, targets):
         sc = self.lambda_sc > 0 and self.solar_correction_enabled
-        spec = LossSpec(color_mode=2, has_sc=sc, sc_lambda=float(self.lambda_sc))
-        loss, terms = fused_loss(spec, inputs, {"gt_rgb": targets})
-        return loss, _pick(terms, ["coarse_color", "coarse_logbeta"] + _sc_keys(sc))
+        return (LossSpec(color_mode=2, has_sc=sc, sc_lambda=float(self.lambda_sc)), {"gt_rgb": targets},
+                ["coarse_color", "coarse_logbeta"] + _sc_keys(sc))
+
+    def forward(self, inputs, targets):
+        return run_plans([self.plan(inputs, targets)], inputs)
 
 
 class DepthLoss(torch.nn.Module):

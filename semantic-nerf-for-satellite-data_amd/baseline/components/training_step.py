@@ -4,12 +4,23 @@ import torch
 from ...framework.components.training_step import BaseTrainingStep
 
 
-def color_and_depth_losses(pipeline, batch, results):
+def color_and_depth_losses(pipeline, batch, results, more_plans=()):
     """colour loss by epoch (SNerfLoss before `first_beta_epoch`, SatNerfLoss after) + the depth-supervision branch while
-    `train_steps < ds_drop`; the log keys and the gate order are the reference's (they are what its TensorBoard shows)."""
+    `train_steps < ds_drop`; the log keys and the gate order are the reference's (they are what its TensorBoard shows).
+    `more_plans`: plans of further loss modules on the SAME rendered tensors (the semantic step's: loss_ops.run_plans evaluates them
+    with the colour loss in one fused call); their terms come back in the same dict, their sum in the same total."""
+    from ...loss_ops import run_plans
     pc = pipeline.cfgs.pipeline
     with_beta = pipeline.get_current_epoch() >= pc.first_beta_epoch
-    total, terms = (pipeline.loss if with_beta else pipeline.loss_without_beta)(results, batch["rgb"]["rgbs"])
+    color = pipeline.loss if with_beta else pipeline.loss_without_beta
+    if hasattr(color, "plan"):
+        total, terms = run_plans([color.plan(results, batch["rgb"]["rgbs"])] + list(more_plans), results)
+    else:      # a foreign colour loss module: called as the reference calls it, the other modules' plans on their own
+        total, terms = color(results, batch["rgb"]["rgbs"])
+        if more_plans:
+            t2, d2 = run_plans(list(more_plans), results)
+            total = total + t2
+            terms.update(d2)
     pipeline.log("train/beta_loss_activated", 1.0 if with_beta else 0.0)
     if not pc.depth_enabled:
         return total, terms

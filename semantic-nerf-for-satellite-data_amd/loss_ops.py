@@ -145,3 +145,52 @@ def fused_loss(spec: LossSpec, results: dict, aux: dict, typ: str = "coarse", sy
         aux["transparency_sc"] = get("transparency_sc")
         aux["weights_sc"] = get("weights_sc")
     return _FusedLoss.apply(spec, aux, sync, *diff)
+
+
+# ---- several loss modules, one fused call ----------------------------------------------------------------------------
+# The reference evaluates its losses module by module (SatNerfLoss, SemanticLoss, SemanticCarRegLoss: three passes over the same
+# rendered tensors).  The fused kernels take ONE configuration with every term switched on or off, so modules whose terms do not
+# collide run as one call: one partial / finish pair, one all-reduce of the totals under data parallelism, one backward scale --
+# and the gradients of tensors several terms share (weights, beta) come out summed.  A module describes its call as a PLAN
+# (LossSpec, aux dict, loss_dict keys); fused_loss(spec, ...) of a single plan is what its forward() does.
+_MERGE = __import__("os").environ.get("SNERF_MERGE_LOSSES", "1") != "0"      # 0: module by module, as the reference evaluates them (A/B)
+_GROUPS = (("color_mode", ("color_mode", "has_sc", "sc_lambda")),
+           ("sem_mode", ("sem_mode", "ignore_index", "use_sbeta", "detach_beta_for_s", "lambda_s", "n_classes")),
+           ("car_reg", ("car_reg", "car_label", "lambda_c")),
+           ("has_depth", ("has_depth", "ds_lambda")))
+
+
+def merge_plans(plans):
+    """-> one (spec, aux, keys) equal to the SUM of the plans, or None when two of them own the same group of terms (two colour
+    losses, say) or disagree about a target tensor."""
+    plans = list(plans)
+    if len(plans) == 1:
+        return plans[0]
+    fields, aux, keys = {}, {}, []
+    for switch, names in _GROUPS:
+        owners = [pl for pl in plans if getattr(pl[0], switch)]
+        if len(owners) > 1:
+            return None
+        if owners:
+            fields.update({n: getattr(owners[0][0], n) for n in names})
+    for _spec, a, k in plans:
+        for name, v in a.items():
+            if name in aux and aux[name] is not v:      # (also: one module masked, the other not -- one call has ONE mask)
+                return None
+            aux[name] = v
+        keys += [x for x in k if x not in keys]
+    return LossSpec(**fields), aux, keys
+
+
+def run_plans(plans, results, typ: str = "coarse", sync: bool = True):
+    """Evaluate loss plans on one set of rendered tensors: merged into one fused call where they allow it, else one call each.
+    Returns (total, {loss_dict key: term})."""
+    merged = merge_plans(plans) if _MERGE else None
+    todo = [merged] if merged is not None else list(plans)
+    total, out = None, {}
+    idx = {k: i for i, k in enumerate(_lib.LOSS_TERMS)}
+    for spec, aux, keys in todo:
+        t, terms = fused_loss(spec, results, aux, typ, sync)
+        total = t if total is None else total + t
+        out.update({k: terms[idx[k]] for k in keys})
+    return total, out

@@ -2,8 +2,7 @@
 loss_dict keys; NaN for an empty car set or an all-ignored CE batch, as in the reference)."""
 import torch
 
-from ...baseline.components.loss import _pick
-from ...loss_ops import LossSpec, fused_loss
+from ...loss_ops import LossSpec, run_plans
 
 
 def _n_classes(inputs):
@@ -16,11 +15,13 @@ class SemanticLoss(torch.nn.Module):
         self.lambda_s = lambda_s
         self.ignore_index = car_index if ignore_car_index else -100
 
-    def forward(self, inputs, targets, ignore_mask=None):
+    def plan(self, inputs, targets, ignore_mask=None):
         spec = LossSpec(sem_mode=1, ignore_index=int(self.ignore_index), lambda_s=float(self.lambda_s),
                         n_classes=_n_classes(inputs))
-        loss, terms = fused_loss(spec, inputs, {"labels": targets, "mask": ignore_mask})
-        return loss, _pick(terms, ["coarse_semantic"])
+        return spec, {"labels": targets, "mask": ignore_mask}, ["coarse_semantic"]
+
+    def forward(self, inputs, targets, ignore_mask=None):
+        return run_plans([self.plan(inputs, targets, ignore_mask)], inputs)
 
 
 class SemanticUncertaintyLoss(torch.nn.Module):
@@ -30,12 +31,14 @@ class SemanticUncertaintyLoss(torch.nn.Module):
         self.ignore_index = car_index if ignore_car_index else -100
         self.detach_beta_for_s = detach_beta_for_s
 
-    def forward(self, inputs, targets, ignore_mask=None):
+    def plan(self, inputs, targets, ignore_mask=None):
         sbeta = "beta_semantic_coarse" in inputs
         spec = LossSpec(sem_mode=2, ignore_index=int(self.ignore_index), lambda_s=float(self.lambda_s),
                         use_sbeta=sbeta, detach_beta_for_s=bool(self.detach_beta_for_s), n_classes=_n_classes(inputs))
-        loss, terms = fused_loss(spec, inputs, {"labels": targets, "mask": ignore_mask})
-        return loss, _pick(terms, ["coarse_semantic"] + (["coarse_semantic_logbeta"] if sbeta else []))
+        return spec, {"labels": targets, "mask": ignore_mask}, ["coarse_semantic"] + (["coarse_semantic_logbeta"] if sbeta else [])
+
+    def forward(self, inputs, targets, ignore_mask=None):
+        return run_plans([self.plan(inputs, targets, ignore_mask)], inputs)
 
 
 class SemanticCarRegLoss(torch.nn.Module):
@@ -46,7 +49,9 @@ class SemanticCarRegLoss(torch.nn.Module):
         self.lambda_c = lambda_c
         self.car_label = car_label
 
+    def plan(self, inputs, targets, ignore_mask=None):
+        return (LossSpec(car_reg=True, car_label=int(self.car_label), lambda_c=float(self.lambda_c)),
+                {"labels": targets, "mask": ignore_mask}, ["coarse_car_reg_loss"])
+
     def forward(self, inputs, targets, ignore_mask=None):
-        spec = LossSpec(car_reg=True, car_label=int(self.car_label), lambda_c=float(self.lambda_c))
-        loss, terms = fused_loss(spec, inputs, {"labels": targets, "mask": ignore_mask})
-        return loss, _pick(terms, ["coarse_car_reg_loss"])
+        return run_plans([self.plan(inputs, targets, ignore_mask)], inputs)

@@ -9,22 +9,20 @@ class RSSemanticTrainingStep(BaseTrainingStep):
     def training_step(self, pipeline, batch, batch_idx):
         pc = pipeline.cfgs.pipeline
         results = pipeline({"rays": batch["rgb"]["rays"], "extras": batch["rgb"]["extras"]})
-        loss, loss_dict = color_and_depth_losses(pipeline, batch, results)
         labels = batch["rgb"]["semantic"]
         mask = batch["rgb"].get("semantic_sparsity_mask")
+        # the reference's gates and log keys; the gated modules hand over their PLANS and are evaluated with the colour loss in
+        # one fused call (loss_ops.run_plans): loss = colour + semantic (+ L_t), loss_dict = the union of their terms, as before
         if pipeline.get_current_epoch() < pc.first_beta_epoch or not pc.use_beta_for_s:
-            semantic_loss, semantic_loss_dict = pipeline.semantic_loss(results, labels, mask)
+            plans = [pipeline.semantic_loss.plan(results, labels, mask)]
             pipeline.log("train/semantic_beta_loss_activated", 0.0)
         else:
-            semantic_loss, semantic_loss_dict = pipeline.uncertainty_semantic_loss(results, labels, mask)
+            plans = [pipeline.uncertainty_semantic_loss.plan(results, labels, mask)]
             pipeline.log("train/semantic_beta_loss_activated", 1.0)
-        loss = loss + semantic_loss
-        loss_dict.update(semantic_loss_dict)
         if pc.use_car_reg_loss and pipeline.get_current_epoch() >= pc.car_reg_loss_start:
-            car_reg_loss, car_reg_loss_dict = pipeline.car_reg_loss(results, labels, mask)
-            loss = loss + car_reg_loss
-            loss_dict.update(car_reg_loss_dict)
+            plans.append(pipeline.car_reg_loss.plan(results, labels, mask))
             pipeline.log("train/car_reg_loss_activated", 1.0)
+        loss, loss_dict = color_and_depth_losses(pipeline, batch, results, more_plans=plans)
         if pipeline.log_metrics:
             pipeline.log("train/semantic_accuracy", semantic_accuracy(results, labels))
         return results, loss, loss_dict

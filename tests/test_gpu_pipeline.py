@@ -161,6 +161,54 @@ def test_loss_modules_vs_oracle(N, S):
             assert rel_err(gh.cpu(), go) <= 2e-5 or max_abs(gh.cpu(), go) <= 1e-9, (name, k, rel_err(gh.cpu(), go))
 
 
+@pytest.mark.parametrize("N,S,sem", [(77, 16, "plain"), (4096, 64, "plain"), (4096, 96, "uncertainty"), (513, 64, "uncertainty_sbeta")])
+def test_merged_loss_call_equals_module_by_module(N, S, sem):
+    """The training steps evaluate colour + semantic (+ L_t) losses as ONE fused call (loss_ops.run_plans).  Against the same modules
+    called one by one, as the reference does: the same loss_dict, the same total and the same gradient on every rendered tensor --
+    also on weights / beta, where the colour loss, the beta-weighted CE and L_t all contribute."""
+    from snerf_amd import loss_ops
+    from snerf_amd.baseline.components.loss import SatNerfLoss
+    from snerf_amd.semantic.components.loss import SemanticLoss, SemanticUncertaintyLoss, SemanticCarRegLoss
+    C = 5
+    g = torch.Generator().manual_seed(N + S)
+    gt = torch.rand(N, 3, generator=g).to(DEV)
+    labels = torch.randint(0, C, (N, 1), generator=g).to(DEV)
+    mask = (torch.rand(N, generator=g) > 0.3).to(DEV)
+    color = SatNerfLoss(lambda_sc=0.05)
+    semantic = SemanticLoss(0.04, 4, ignore_car_index=True) if sem == "plain" else SemanticUncertaintyLoss(0.04, 4, ignore_car_index=True)
+    car = SemanticCarRegLoss(0.1, 4)
+    base = _rand_results(N, S, C, 7 + S, sbeta=sem.endswith("sbeta"))
+    ra = {k: v.clone().to(DEV).requires_grad_(True) for k, v in base.items()}
+    rb = {k: v.clone().to(DEV).requires_grad_(True) for k, v in base.items()}
+    # module by module
+    total_a, dict_a = color(ra, gt)
+    for m in (semantic, car):
+        t, d = m(ra, labels, mask)
+        total_a = total_a + t
+        dict_a.update(d)
+    # one call
+    plans = [color.plan(rb, gt), semantic.plan(rb, labels, mask), car.plan(rb, labels, mask)]
+    assert loss_ops.merge_plans(plans) is not None
+    total_b, dict_b = loss_ops.run_plans(plans, rb)
+    assert set(dict_a) == set(dict_b)
+    for k in dict_a:
+        assert abs(float(dict_a[k]) - float(dict_b[k])) <= 1e-6 * max(1.0, abs(float(dict_a[k]))), k
+    assert abs(float(total_a) - float(total_b)) <= 2e-6 * max(1.0, abs(float(total_a)))
+    total_a.backward()
+    total_b.backward()
+    for k in base:
+        ga, gb = ra[k].grad, rb[k].grad
+        if ga is None or float(ga.abs().max()) == 0.0:
+            assert gb is None or float(gb.abs().max()) == 0.0, k
+            continue
+        assert rel_err(gb.cpu(), ga.cpu()) <= 2e-6, (k, rel_err(gb.cpu(), ga.cpu()))
+    # two modules that own the same terms do not merge: evaluated one by one, summed
+    two = [color.plan(rb, gt), SatNerfLoss(lambda_sc=0.0).plan(rb, gt)]
+    assert loss_ops.merge_plans(two) is None
+    t2, _ = loss_ops.run_plans(two, {k: v.detach() for k, v in rb.items()})
+    assert torch.isfinite(t2)
+
+
 def test_loss_nan_semantics():
     """empty car set -> NaN L_t; every target ignored -> NaN CE (reference behaviour, SURVEY hard parts)"""
     from snerf_amd.semantic.components.loss import SemanticLoss, SemanticCarRegLoss

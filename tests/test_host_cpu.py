@@ -247,3 +247,24 @@ def test_ray_bank_per_image_sizes():
     assert plain.n_images(6) == 3 and plain.image(2, 6)["rays"][:, 0].tolist() == list(range(12, 18))
     with pytest.raises(ValueError):
         plain.n_images()
+
+
+def test_loss_plans_merge_by_term_groups():
+    """loss_ops.merge_plans: modules whose terms do not collide become one configuration (field by field from the module that owns the
+    group), the targets are united, the loss_dict keys concatenated; colliding owners or different target tensors do not merge."""
+    import torch
+    from snerf_amd.loss_ops import LossSpec, merge_plans
+    gt, labels, mask = torch.zeros(4, 3), torch.zeros(4, 1, dtype=torch.long), torch.ones(4, dtype=torch.bool)
+    color = (LossSpec(color_mode=2, has_sc=True, sc_lambda=0.05), {"gt_rgb": gt}, ["coarse_color", "coarse_logbeta", "coarse_sc_term2", "coarse_sc_term3"])
+    sem = (LossSpec(sem_mode=1, ignore_index=4, lambda_s=0.04, n_classes=5), {"labels": labels, "mask": mask}, ["coarse_semantic"])
+    car = (LossSpec(car_reg=True, car_label=4, lambda_c=0.1), {"labels": labels, "mask": mask}, ["coarse_car_reg_loss"])
+    spec, aux, keys = merge_plans([color, sem, car])
+    assert spec == LossSpec(color_mode=2, has_sc=True, sc_lambda=0.05, sem_mode=1, ignore_index=4, lambda_s=0.04, n_classes=5,
+                            car_reg=True, car_label=4, lambda_c=0.1)
+    assert aux["gt_rgb"] is gt and aux["labels"] is labels and aux["mask"] is mask
+    assert keys == color[2] + sem[2] + car[2]
+    assert merge_plans([color]) is color
+    assert merge_plans([color, (LossSpec(color_mode=1), {"gt_rgb": gt}, ["coarse_color"])]) is None          # two colour losses
+    assert merge_plans([sem, (car[0], {"labels": labels.clone(), "mask": mask}, car[2])]) is None              # different label tensors
+    nomask = (car[0], {"labels": labels, "mask": None}, car[2])
+    assert merge_plans([sem, nomask]) is None                                                                  # one call has one mask
