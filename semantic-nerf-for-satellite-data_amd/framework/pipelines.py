@@ -6,7 +6,9 @@ _init_training_step, models registered as attributes model_<key> so state_dict k
 `model_<key>.` prefix that load_ckpoint.py:94-129 filters on), and `run_pipeline` is a small
 single-process-per-GPU loop (Adam + StepLR per epoch, gradient all-reduce under torch.distributed)."""
 import abc
+import collections
 import importlib
+import os
 import time
 
 import torch
@@ -123,9 +125,17 @@ class TrainLoop:
         self.bucket = None
         self.shuffle = bool(cfgs.run.shuffle_dataset)
         self.exchange_events = None      # bench: a list -> (start, end) HIP events around the gradient all-reduce of every step
+        # The host issues a step in ~2 ms, the device runs it in ~26: unchecked, the host runs ahead until the HIP queue is full, and
+        # every step it is ahead keeps that step's result and gradient tensors alive in the caching allocator (more device memory,
+        # fresh hipMallocs deep into a run).  The loop therefore waits, before issuing step n, for the END of step n - MAX_LEAD:
+        # the device always has a whole step queued behind the running one, the host is never further ahead than that.
+        self.max_lead = int(os.environ.get("SNERF_MAX_LEAD", "2"))
+        self._in_flight = collections.deque()
 
     def step(self, step: int):
         pl = self.pipeline
+        while self.max_lead > 0 and len(self._in_flight) >= self.max_lead:
+            self._in_flight.popleft().synchronize()
         pl.current_epoch = step // self.steps_per_epoch
         batch = {"rgb": self.bank.batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)}
         if "depth" in pl.datasets:
@@ -152,6 +162,10 @@ class TrainLoop:
         self.optimizer.step()
         if (step + 1) % self.steps_per_epoch == 0:
             self.scheduler.step()
+        if self.max_lead > 0 and self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            self._in_flight.append(ev)
         return out
 
 
