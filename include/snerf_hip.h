@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNERF_ABI_VERSION 3
+#define SNERF_ABI_VERSION 4
 #define SNERF_MAX_LAYERS 16
 
 /* error codes */

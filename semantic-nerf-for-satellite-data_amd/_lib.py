@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SNERF_LIB_PATH: an alternative build of the library (ablation harness of tools/ablate; diagnostics only)
 LIB_PATH = os.environ.get("SNERF_LIB_PATH") or os.path.join(_HERE, "libsnerf_hip.so")
 MAX_LAYERS = 16
-ABI_VERSION = 3   # include/snerf_hip.h SNERF_ABI_VERSION
+ABI_VERSION = 4   # include/snerf_hip.h SNERF_ABI_VERSION
 
 FLAG_TRAIN = 1
 FLAG_SC_PASS = 2
