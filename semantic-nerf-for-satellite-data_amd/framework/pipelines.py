@@ -131,15 +131,50 @@ class TrainLoop:
         # the device always has a whole step queued behind the running one, the host is never further ahead than that.
         self.max_lead = int(os.environ.get("SNERF_MAX_LEAD", "2"))
         self._in_flight = collections.deque()
+        # The reference's DataLoader workers have the next batch ready when a step ends.  Here the batch is five row gathers from
+        # the HBM-resident ray bank -- tiny kernels that depend on nothing the optimiser writes, but on the compute stream they sat
+        # between Adam and the first kernel of the next forward.  They are issued for step n + 1 on a data stream of their own when
+        # step n has been issued, run beside its kernels, and the next step only waits for their event.  (SNERF_PREFETCH=0: in line.)
+        self.prefetch = os.environ.get("SNERF_PREFETCH", "1") != "0" and self.device.type == "cuda"
+        self._data_stream = torch.cuda.Stream(device=self.device) if self.prefetch else None
+        self._next = None                # (step, batch, event) issued ahead on the data stream
+
+    def _make_batch(self, step: int):
+        batch = {"rgb": self.bank.batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)}
+        if "depth" in self.pipeline.datasets:
+            batch["depth"] = self.pipeline.datasets["depth"].batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)
+        return batch
+
+    def _issue_batch(self, step: int):
+        """the batch of `step` on the data stream; the event that marks it ready"""
+        if self._next is None:       # first use: behind whatever built (or moved) the bank on the compute stream
+            self._data_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self._data_stream):
+            batch = self._make_batch(step)
+            ev = torch.cuda.Event()
+            ev.record(self._data_stream)
+        return step, batch, ev
+
+    def _take_batch(self, step: int):
+        if not self.prefetch:
+            return self._make_batch(step)
+        if self._next is None or self._next[0] != step:     # first step, or the caller jumped: issue it now
+            self._next = self._issue_batch(step)
+        _, batch, ev = self._next
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ev)
+        for part in batch.values():
+            for t in part.values():
+                if torch.is_tensor(t):
+                    t.record_stream(main)      # allocated on the data stream, consumed (and freed) on the compute stream
+        return batch
 
     def step(self, step: int):
         pl = self.pipeline
         while self.max_lead > 0 and len(self._in_flight) >= self.max_lead:
             self._in_flight.popleft().synchronize()
         pl.current_epoch = step // self.steps_per_epoch
-        batch = {"rgb": self.bank.batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)}
-        if "depth" in pl.datasets:
-            batch["depth"] = pl.datasets["depth"].batch(step, self.global_batch, self.rank, self.world, shuffle=self.shuffle)
+        batch = self._take_batch(step)
         self.optimizer.zero_grad()
         pl.logged = {k: v for k, v in pl.logged.items() if not k.startswith("train/")}   # a step reports only what IT logged (no stale terms of dropped losses)
         out = pl.training_step(batch, step)
@@ -166,6 +201,8 @@ class TrainLoop:
             ev = torch.cuda.Event()
             ev.record()
             self._in_flight.append(ev)
+        if self.prefetch:
+            self._next = self._issue_batch(step + 1)
         return out
 
 
