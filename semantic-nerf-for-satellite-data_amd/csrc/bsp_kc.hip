@@ -432,11 +432,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     // half-block are therefore kept alive (keep_planes) until the read-back has been consumed.
     auto keep_planes = [](const u32x4 (&hi)[2], const u32x4 (&lo)[2]) { asm volatile("" ::"v"(hi[0]), "v"(lo[0]), "v"(hi[1]), "v"(lo[1])); };
     auto strip_flush = [&](int mi, int nj) {     // rows beyond I are rejected by the descriptor
+      // two read-backs in flight, then their two stores: two LDS latencies per flush instead of four in a row (all four at once
+      // cost 16 registers the first flushes of a tile do not have: four instantiations spilled)
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) {
-        const u32x4 d = *reinterpret_cast<const u32x4*>(strip + sr_off + 1024 * ps);
-        __builtin_amdgcn_raw_buffer_store_b128(d, srdC, voC[nj], (unsigned)(4 * mi + ps) * stepC8, 2);
-        store_data_guard(d);
+      for (int pp = 0; pp < 4; pp += 2) {
+        const u32x4 d0 = *reinterpret_cast<const u32x4*>(strip + sr_off + 1024 * pp);
+        const u32x4 d1 = *reinterpret_cast<const u32x4*>(strip + sr_off + 1024 * (pp + 1));
+        __builtin_amdgcn_raw_buffer_store_b128(d0, srdC, voC[nj], (unsigned)(4 * mi + pp) * stepC8, 2);
+        store_data_guard(d0);
+        __builtin_amdgcn_raw_buffer_store_b128(d1, srdC, voC[nj], (unsigned)(4 * mi + pp + 1) * stepC8, 2);
+        store_data_guard(d1);
       }
     };
     float bj[4][8];
