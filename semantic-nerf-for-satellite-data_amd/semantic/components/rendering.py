@@ -58,11 +58,15 @@ def fused_model_rendering(renderer, models, typ, rays, extras, render_options, i
             z_given = ops.sample_z(rays, z_steps_on(rays.device, renderer.N_samples), opts.get("perturb_rand"))
             pin = ops.PassInputs(sun_d=sun_d, rays=rays, z_vals=z_given)
         main = torch.cuda.current_stream(rays.device)
-        side.wait_stream(main)
+        side.wait_stream(main)      # (before the main pass is issued: the side stream waits for the weights pack and z, not for that pass)
+        # The main pass is CREATED first: autograd runs the younger node first, so in the backward the solar-correction pass -- the
+        # shorter one, done ~2 ms before the main pass -- adds its gradients into the optimiser's bucket first and the main pass's
+        # unpack only waits for an event that completed long ago.  The other way round the short pass queued behind the long one's
+        # unpack at the very end of the step: two cross-stream hand-overs (~15-25 us each) and its unpack kernels, all exposed.
+        result = ops.render_pass(model.spec, params, pin, rays_t, rays_t_s, packed=packed)
         with torch.cuda.stream(side):
             sc = ops.render_pass(model.spec, params, ops.PassInputs(sun_d=sun_d, rays=rays, z_vals=z_given), rays_t,
                                  rays_t_s, sc_pass=True, packed=packed)
-        result = ops.render_pass(model.spec, params, pin, rays_t, rays_t_s, packed=packed)
         main.wait_stream(side)
         for v in sc.values():
             v.record_stream(main)
