@@ -121,6 +121,39 @@ def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
     assert only and all(k.startswith("fc_net") for k in only)
 
 
+@pytest.mark.parametrize("env", [{"SNERF_PREFETCH": "0"}, {"SNERF_MAX_LEAD": "0"}, {"SNERF_MAX_LEAD": "1"}, {"SNERF_MERGE_LOSSES": "0"}])
+def test_trainloop_host_side_switches_do_not_change_the_trajectory(env, monkeypatch):
+    """Batch prefetch on a data stream, the bound on the host's lead and the merged loss call are scheduling: the same seeded steps give
+    the same losses (bit for bit for the first two; the merged loss call sums its terms in one kernel instead of module by module) and
+    the same weights, across an epoch boundary (a new permutation of the bank drawn by the prefetching side) and a jump in the step
+    index (a prefetched batch that is not the one asked for)."""
+    import importlib
+    from snerf_amd import loss_ops
+    def run():
+        loop = _loop(seed=11)
+        spe = loop.steps_per_epoch
+        order = list(range(0, spe + 2)) + [3 * spe + 1, 3 * spe + 2]      # consecutive steps over an epoch boundary, then a jump
+        losses = []
+        for s in order:
+            torch.manual_seed(500 + s)
+            losses.append(float(loop.step(s)["loss"]))
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in loop.pipeline.parameters()]
+    base_l, base_w = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setattr(loss_ops, "_MERGE", env.get("SNERF_MERGE_LOSSES", "1") != "0")
+    got_l, got_w = run()
+    if "SNERF_MERGE_LOSSES" in env:
+        assert np.allclose(base_l, got_l, rtol=2e-6, atol=0), (base_l, got_l)
+        for a_, b_ in zip(base_w, got_w):
+            assert torch.allclose(a_, b_, rtol=0, atol=2e-6)
+    else:
+        assert base_l == got_l, (base_l, got_l)
+        for a_, b_ in zip(base_w, got_w):
+            assert torch.equal(a_, b_)
+
+
 def test_pass_workspaces_are_leased_not_reallocated():
     """Round 3's driver-timed bench lost 240 ms to a hipMalloc of a 10 GB pass workspace INSIDE the timed steps: torch's caching
     allocator had carved a result tensor out of the idle block while the previous step's results were still referenced.  Workspaces are
