@@ -163,8 +163,10 @@ int launch_zero_cols(char* base, size_t pitch, size_t width_bytes, int rows, hip
 // ---- sample position + positional encoding + per-sample extras, as planes ------------------------------------------
 // One workgroup per 128-point block.  gamma(x) is in [-1, 1]: its blocks take the fixed exponent 13; raw positions
 // (baseline SatNeRF: identity encoding) and the extras [sun | t | t_s] get the exponent of their own block maximum.
+// (point indices are below 2^30 -- api.hip: make_plan -- so ray = point / S is a 32-bit division: the 64-bit one this replaces cost
+//  more instructions per item than four of its sincos evaluations)
 __device__ __forceinline__ void point_xyz(const EncodeArgs& a, long long point, float (&x)[3]) {
-  const int n = (int)(point / a.S);
+  const int n = (int)((unsigned)point / (unsigned)a.S);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     if (a.xyz != nullptr) {
@@ -208,7 +210,7 @@ __global__ __launch_bounds__(256) void encode_bsp_kernel(EncodeBsp g) {
       mx = fmaxf(mx, fmaxf(fabsf(x[0]), fmaxf(fabsf(x[1]), fabsf(x[2]))));
     }
   if (g.fa != nullptr) {
-    const int n0 = (int)(p0 / a.S), n1 = (int)((p0 + npts - 1) / a.S);
+    const int n0 = (int)((unsigned)p0 / (unsigned)a.S), n1 = (int)((unsigned)(p0 + npts - 1) / (unsigned)a.S);
     for (int i = t; i < (n1 - n0 + 1) * 16; i += 256) me = fmaxf(me, fabsf(extras_value(a, n0 + (i >> 4), i & 15)));
   }
   const int e_pe = a.F > 0 ? 13 : exp_of_maxbits(__float_as_uint(block_max_256(mx, sm)));
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void encode_bsp_kernel(EncodeBsp g) {
       d = g.pe + (size_t)point * a.Ep * 2 * g.pl + (size_t)grp * 32 * g.pl;
       sc = s_pe;
     } else {
-      const int n = (int)(point / a.S);
+      const int n = (int)((unsigned)point / (unsigned)a.S);
 #pragma unroll
       for (int j = 0; j < 16; ++j) v[j] = extras_value(a, n, j);
       d = g.fa + (size_t)point * a.FA * 2 * g.pl + g16_off(g.fa_col0, g.pl);
