@@ -18,8 +18,8 @@ oracle's gradients of the subset alone.
 
 Tolerances: 1e-4 absolute on every rendered tensor, class argmax exact wherever the oracle's top-2 margin exceeds
 2e-4, z_vals bit-exact, parameter gradients 2e-3 relative L2 (BASELINE.json north_star: 1e-4 outputs, argmax
-bit-exact).  The bf16 mode (REDUCED precision, the reference's `precision = 16`) is judged PSNR-style: outputs
-within 2e-2, loss terms within 1 %, gradients within 5 % -- stated in the test.
+bit-exact).  The bf16 mode (REDUCED precision, the reference's `precision = 16`: here the one-plane mode) is judged
+PSNR-style: outputs within 5e-3, class agreement >= 98 %, loss terms within 1 %, gradients within 3 % -- stated in the test.
 """
 import pytest
 import torch
