@@ -10,6 +10,7 @@ result.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
@@ -153,7 +154,7 @@ def fused_loss(spec: LossSpec, results: dict, aux: dict, typ: str = "coarse", sy
 # collide run as one call: one partial / finish pair, one all-reduce of the totals under data parallelism, one backward scale --
 # and the gradients of tensors several terms share (weights, beta) come out summed.  A module describes its call as a PLAN
 # (LossSpec, aux dict, loss_dict keys); fused_loss(spec, ...) of a single plan is what its forward() does.
-_MERGE = __import__("os").environ.get("SNERF_MERGE_LOSSES", "1") != "0"      # 0: module by module, as the reference evaluates them (A/B)
+_MERGE = os.environ.get("SNERF_MERGE_LOSSES", "1") != "0"      # 0: module by module, as the reference evaluates them (A/B)
 _GROUPS = (("color_mode", ("color_mode", "has_sc", "sc_lambda")),
            ("sem_mode", ("sem_mode", "ignore_index", "use_sbeta", "detach_beta_for_s", "lambda_s", "n_classes")),
            ("car_reg", ("car_reg", "car_label", "lambda_c")),
