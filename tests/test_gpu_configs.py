@@ -173,3 +173,20 @@ def test_c5_raised_embedding_vocab_96():
     step, as in test_c2 (the library's embedding kernels at this vocabulary: test_embedding_rows_forward_backward[96])."""
     cfg = O.OracleCfg(n_samples=64, t_embedding_vocab=96)
     _subset_parity(cfg, 2048, 192, seed=27, epoch=2, n_images=96)
+
+
+@pytest.mark.parametrize("kw", [
+    {"use_separate_beta_for_s": True, "use_beta_for_s": True},                       # a fourth head block: five column tiles in the first head layer
+    {"use_separate_beta_for_s": True, "use_beta_for_s": True, "use_tj_for_s": True},
+    {"use_tj_for_s": True}, {"use_tj_instead_of_beta": True}, {"semantic_activation_function": "none"},
+    {"activation_function": "relu"},                                                  # no folded projections: the 32-wide launches at full width
+    {"n_classes": 4},                                                                 # labels 0..3 valid, 4 = car = the ignore index (outside [0, C): allowed)
+    {"fc_use_full_features": True},                                                   # feat_last = 512: head blocks of two column tiles (no final-layer fold)
+], ids=lambda kw: "+".join(sorted(kw)))
+def test_model_variants_at_full_width(kw):
+    """Every model switch of the reference at fc_units = 512 (where the folded projections -- sigma, sun, and for feat_last = 256 the
+    final head layers with up to five projections per column tile -- replace the 32-wide launches), 256 rays x 32 samples, the WHOLE batch
+    through the oracle: outputs, the epoch-3 loss set (beta-weighted CE where switched on) and every parameter gradient.  The small-width
+    variant tests (tests/test_gpu_kernels.py) run the same switches through the unfolded launches."""
+    cfg = O.OracleCfg(n_samples=32, **kw)
+    _subset_parity(cfg, 256, 256, seed=31, epoch=3)
