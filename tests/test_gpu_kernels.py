@@ -232,7 +232,8 @@ def test_inference_seam_explicit_xyz():
 def test_ragged_and_multi_chunk_sizes():
     """N*S not a multiple of the 128-row tile, S > 64 (two wavefront chunks per ray), S < 64."""
     dev = _dev()
-    for (N, S, W) in [(37, 96, 64), (5, 130, 32), (129, 7, 32), (1, 64, 32)]:
+    # (the two W = 512 sizes: the folded projections' partial sums of a last row tile that is mostly / partly beyond the points)
+    for (N, S, W) in [(37, 96, 64), (5, 130, 32), (129, 7, 32), (1, 64, 32), (3, 130, 512), (37, 96, 512)]:
         cfg = O.OracleCfg(fc_units=W, n_samples=S)
         pn = O.init_params_numpy(cfg, 3)
         emb = torch.from_numpy(O.init_embedding_numpy(cfg, 3))
