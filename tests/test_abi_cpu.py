@@ -122,3 +122,11 @@ def test_param_names_match_reference_state_dict():
         spec = ModelSpec(n_freq=10 if sem else 0, n_classes=5 if sem else 0,
                          use_separate_beta_for_s=cfg.use_separate_beta_for_s)
         assert spec.param_names() == list(O.param_shapes(cfg).keys())
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check (`__graft_entry__.build()`: make for gfx950, import, ABI version): it must not lag behind the
+    header (it once asserted the previous ABI version while every other test was green)."""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
