@@ -13,6 +13,7 @@ struct EncodeArgs {
   int dir_is_sun = 0;            // solar-correction pass: x = o + sun_d * z
   int N = 0, S = 0, F = 0, Ep = 0;
   int FA = 0, W = 0, Xp = 0, x_sun = 0, x_t = 3, x_ts = -1, tau = 0;
+  unsigned* zero = nullptr; int zero_n = 0;   // words the first workgroup clears (the pass's tile counters: one launch less than a kernel of their own)
 };
 
 struct CopyEntry {

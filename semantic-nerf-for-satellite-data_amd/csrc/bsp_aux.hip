@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void encode_bsp_kernel(EncodeBsp g) {
   __shared__ float sm[4];
   const EncodeArgs& a = g.a;
   const int rb = blockIdx.x, t = threadIdx.x;
+  if (rb == 0) for (int i = t; i < a.zero_n; i += 256) a.zero[i] = 0u;   // (nothing before the pass's first GEMM launch reads them)
   const long long P = (long long)a.N * a.S;
   const long long p0 = (long long)rb * 128;
   const int npts = (int)min((long long)128, P - p0);

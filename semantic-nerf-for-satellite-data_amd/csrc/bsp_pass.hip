@@ -47,8 +47,8 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
   const Ws ws{(char*)workspace};
   // tile counters of the K-contiguous launches: one zeroed 64-byte slot per launch, in launch order.  (Zeroed by a kernel:
   // with hipMemsetAsync the forward's and the backward's memset of this region became two identical memset nodes of a
-  // captured HIP graph, and replays on ROCm 7.2 then ran the backward's launches on counters that had not been zeroed.)
-  RC(bsp::launch_zero_cols(ws.c(p.o_kcq), (size_t)KCQ_SLOTS * 64, (size_t)KCQ_SLOTS * 64, 1, st));
+  // captured HIP graph, and replays on ROCm 7.2 then ran the backward's launches on counters that had not been zeroed.)  The first
+  // kernel of the pass does it on the side: the encode kernel here, the composite backward in backward_bsp.
   int kcq = 0;
   auto launch_kc = [&](bsp::KcArgs& g) { g.rev = kcq & 1; g.tile_ctr = kcq < KCQ_SLOTS ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
   const int P = p.P, W = p.W, H = p.H;
@@ -64,6 +64,7 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
   ea.dir_is_sun = (p.sc && !in->xyz) ? 1 : 0;
   ea.N = p.N; ea.S = p.S; ea.F = p.F; ea.Ep = p.Ep;
   ea.FA = p.FA; ea.W = p.Wf; ea.Xp = p.Xp; ea.x_sun = p.x_sun; ea.x_t = p.x_t; ea.x_ts = p.x_ts; ea.tau = p.tau;
+  ea.zero = ws.u(p.o_kcq); ea.zero_n = KCQ_SLOTS * 16;
   RC(bsp::launch_encode_bsp(ea, ws.c(p.o_pe), ws.i(p.e_pe), ws.c(p.o_fa), ws.i(p.e_fa), p.Wf, p.pl, st));
   const size_t EB = 2 * (size_t)p.pl;   // bytes per element of a plane tensor
   if (p.Wf > W)   // pad columns between feats and extras (narrow test networks only): zero planes, read against zero weights
@@ -230,8 +231,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
                  void* workspace, hipStream_t st) {
   const Ws ws{(char*)workspace};
   const int P = p.P, W = p.W, H = p.H;
-  RC(bsp::launch_zero_cols(ws.c(p.o_kcq), (size_t)KCQ_SLOTS * 64, (size_t)KCQ_SLOTS * 64, 1, st));
-  int kcq = 0;
+  int kcq = 0;     // (the counters are cleared by the composite backward kernel, the first launch of this pass)
   auto launch_kc = [&](bsp::KcArgs& g) { g.rev = kcq & 1; g.tile_ctr = kcq < KCQ_SLOTS ? ws.i(p.o_kcq) + 16 * kcq++ : nullptr; return bsp::launch_kc(g, st); };
   // activation derivative in a dX epilogue, rebuilt from the stored activation h (planes o_h / exponents e_h, leading
   // dimension ld, column col0): siren w0 * sign(cos) * sqrt(1 - h^2) with the sign words o_c; relu: h > 0
@@ -256,6 +256,7 @@ int backward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sn
   b.g_albedo = go->albedo; b.g_sun = go->sun; b.g_sky = go->sky; b.g_beta = go->beta; b.g_sigmas = go->sigmas;
   b.g_beta_s = go->beta_semantic; b.g_logits = go->semantic_logits;
   b.d_sigo = dsig; b.d_fino = dfin; b.d_suno = dsun; b.sky_slab = p.sc ? nullptr : ws.f(p.o_skyslab);
+  b.zero = ws.u(p.o_kcq); b.zero_n = KCQ_SLOTS * 16;
   RC(launch_composite_bwd(b, st));
   if (!p.sc)
     RC(red_add_col(rq.col, ws.f(p.o_skyslab), p.comp_blocks * 4, (size_t)p.sky_floats, p.sky_floats, gp + p.sky));

@@ -35,6 +35,7 @@ struct CompBwdArgs {
   const float* g_beta_s = nullptr; const float* g_logits = nullptr;
   float* d_sigo = nullptr; float* d_fino = nullptr; float* d_suno = nullptr;  // [P][NARROW]
   float* sky_slab = nullptr;  // [waves][9H+4]
+  unsigned* zero = nullptr; int zero_n = 0;   // words the first workgroup clears (the backward pass's tile counters)
 };
 
 int launch_composite_fwd(const CompArgs& a, hipStream_t st);

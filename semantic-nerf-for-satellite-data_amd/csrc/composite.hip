@@ -175,6 +175,7 @@ int launch_composite_fwd(const CompArgs& a, hipStream_t st) {
 //   dL/dalpha_j = G_j T_j - (sum_{j'>j} Hd_j' T_j') / tau_j,  Hd_j = g_T[j] + G_j alpha_j
 // (same algebra as torch's cumprod backward for non-zero inputs: tau_j >= 1e-10).
 __global__ __launch_bounds__(256) void composite_bwd_kernel(CompBwdArgs b) {
+  if (blockIdx.x == 0) for (int i = threadIdx.x; i < b.zero_n; i += 256) b.zero[i] = 0u;
   const CompArgs& a = b.f;
   const int lane = threadIdx.x & 63;
   const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
