@@ -16,13 +16,12 @@ def get_xyz_from_nerf_prediction(rays: torch.Tensor, depth: torch.Tensor) -> tor
 
 
 @torch.no_grad()
-def extract_pointcloud(cfgs, renderer, models, rays, extras, render_options=None, with_labels=None, sharded=None):
+def extract_pointcloud(cfgs, renderer, models, rays, extras, render_options=None, with_labels=None, sharded=False):
     """One image -> {"xyz_n" (R,3) f64, "colors" (R,3) f32, "depth" (R) f32 [, "labels" (R) i64]}, all on the device.
-    Under a process group (`sharded` None: whenever world size > 1) the image's rays are rendered in rank shards and the
-    per-ray results gathered, so every rank returns the whole cloud (eval/utils/util.py: sharded_lean_inference)."""
-    from .. import parallel
-    if sharded is None:
-        sharded = parallel.world()[1] > 1
+    `sharded=False` (default) is the reference's single-device call: safe from one rank of a process group (the usual export
+    inside a data-parallel run).  `sharded=True` is a COLLECTIVE: every rank of the group must call it with the same rays;
+    the image is rendered in rank shards and the per-ray results gathered, so every rank returns the whole cloud
+    (eval/utils/util.py: sharded_lean_inference)."""
     sem = models["coarse"].spec.n_classes > 0
     if with_labels is None:
         with_labels = sem

@@ -51,6 +51,9 @@ def lean_inference(cfgs, renderer, models, rays, extras, keys=("rgb_coarse", "de
     tensors unless asked for), the solar-correction pass is skipped unless one of its results is requested, and the
     weights are packed once for all chunks."""
     from ... import ops
+    # full-frame inference has its own memory profile: the idle TRAINING workspaces (8-20 GB each, held outside torch's allocator
+    # by the lease pool) go back to torch first, so a frame's result tensors and inference workspace can use that memory
+    ops.release_workspaces()
     chunk = cfgs.pipeline.render_chunk_size
     n = rays.shape[0]
     S = cfgs.pipeline.n_samples

@@ -147,7 +147,9 @@ class TrainLoop:
 
     def _issue_batch(self, step: int):
         """the batch of `step` on the data stream; the event that marks it ready"""
-        if self._next is None:       # first use: behind whatever built (or moved) the bank on the compute stream
+        if self._next is None or self._next[0] != step - 1:
+            # first use, or the caller jumped (resume, evaluation in between): behind whatever built, moved or touched the bank
+            # on the compute stream since.  The steady state (step n + 1 issued right after step n) needs no such wait.
             self._data_stream.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(self._data_stream):
             batch = self._make_batch(step)

@@ -195,7 +195,13 @@ def lease_workspace(dev, nbytes: int) -> _WsLease:
         if _WS_POISON:
             t.fill_(0xFF)
     else:
-        t = _empty(nbytes, dtype=torch.uint8, device=dev)
+        try:
+            t = _empty(nbytes, dtype=torch.uint8, device=dev)
+        except torch.cuda.OutOfMemoryError:
+            # the idle workspaces of other shapes / streams live outside torch's allocator: give them back and try once more
+            release_workspaces()
+            torch.cuda.empty_cache()
+            t = _empty(nbytes, dtype=torch.uint8, device=dev)
     return _WsLease(key, t)
 
 
@@ -436,7 +442,10 @@ class _RenderPass(torch.autograd.Function):
             setattr(so, k, v.data_ptr())
         so.semantic_label = label.data_ptr() if label is not None else None
         if pin.z_vals is not None and pin.z_vals.is_contiguous() and pin.z_vals.dtype == torch.float32:
-            z_out = pin.z_vals.detach()          # depths given: they ARE the result (no copy-out launch)
+            # depths given: they ARE the result (no copy-out launch).  ALIASING: results["z_vals"] shares storage with the caller's
+            # tensor -- in fused_model_rendering the main pass's result, the sc pass's input and its result are one buffer, which
+            # the backward passes read again.  Never edit it in place (tests/test_gpu_kernels.py pins the contract).
+            z_out = pin.z_vals.detach()
         else:
             z_out = _empty((N, S), dtype=torch.float32, device=dev)
             so.z_vals = z_out.data_ptr()
@@ -513,7 +522,8 @@ class _RenderPass(torch.autograd.Function):
 def render_pass(spec: ModelSpec, params: dict, pin: PassInputs, t: torch.Tensor, t_s: torch.Tensor | None = None,
                 sc_pass: bool = False, packed: torch.Tensor | None = None) -> dict:
     """Run one pass (main, or the solar-correction variant) and return the reference's result dict
-    (semantic/models/rs_semantic.py:111-128) plus 'z_vals'."""
+    (semantic/models/rs_semantic.py:111-128) plus 'z_vals'.  When `pin.z_vals` is given (contiguous fp32), the returned
+    'z_vals' IS that tensor's storage (no copy): do not edit either in place while the pass's backward is pending."""
     names = spec.param_names()
     plist = [params[n] for n in names]
     if packed is None:

@@ -17,8 +17,8 @@ oracle's gradients of the subset alone.
 | c5 four scenes 32768 x 128 on 8 GPUs, bf16 | 4096 x 128 | test_c5_* (bf16 mode; full-frame half: tests/test_gpu_pipeline.py) |
 
 Tolerances: 1e-4 absolute on every rendered tensor, class argmax exact wherever the oracle's top-2 margin exceeds
-2e-4, z_vals bit-exact, parameter gradients 2e-3 relative L2 (BASELINE.json north_star: 1e-4 outputs, argmax
-bit-exact).  The bf16 mode (REDUCED precision, the reference's `precision = 16`: here the one-plane mode) is judged
+twice the measured logit error, z_vals bit-exact, parameter gradients 2e-4 relative L2 (GRAD_REL_TOL: ten times the largest
+error measured on any tensor of any case; BASELINE.json north_star: 1e-4 outputs, argmax bit-exact).  The bf16 mode (REDUCED precision, the reference's `precision = 16`: here the one-plane mode) is judged
 PSNR-style: outputs within 5e-3, class agreement >= 98 %, loss terms within 1 %, gradients within 3 % -- stated in the test.
 """
 import pytest

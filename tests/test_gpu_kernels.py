@@ -68,6 +68,27 @@ def _hip_render(cfg, gp, emb_g, b, dev, emb_s_g=None):
     return out
 
 
+def test_given_depths_are_returned_as_the_callers_storage():
+    """Contract (ops.render_pass): when the depths are GIVEN (seam 3, the solar-correction pass), results['z_vals'] is the caller's own
+    tensor, not a copy -- no copy-out launch.  Main pass result, sc pass input and sc pass result are then ONE buffer: whoever edits it
+    in place edits all three (and the depths a later backward reads).  No caller in the package does; this test makes the aliasing explicit."""
+    from snerf_amd import ops
+    dev = _dev()
+    cfg = O.OracleCfg(fc_units=32, n_samples=16)
+    spec = _spec(cfg)
+    gp = _gpu_params(O.init_params_numpy(cfg, 3), dev)
+    b = O.batch_to_torch(O.synthetic_batch(24, 16, seed=9))
+    rays, extras, u = b["rays"].to(dev), b["extras"].to(dev), b["u"].to(dev)
+    t = torch.zeros(24, cfg.t_embedding_tau, device=dev)
+    with torch.no_grad():
+        res = ops.render_pass(spec, gp, ops.PassInputs(sun_d=extras[:, :3], rays=rays, z_steps=torch.linspace(0, 1, 16).to(dev), u=u), t, None)
+        z_main = res["z_vals"]
+        sc = ops.render_pass(spec, gp, ops.PassInputs(sun_d=extras[:, :3], rays=rays, z_vals=z_main), t, None, sc_pass=True)
+    assert z_main.data_ptr() != u.data_ptr()                      # sampled depths: a fresh tensor
+    assert sc["z_vals"].data_ptr() == z_main.data_ptr()          # given depths: the caller's storage
+    assert torch.equal(sc["z_vals"], z_main)
+
+
 LABEL_STATS = []   # one record per comparison: how many rays qualified for the exact-label check, disagreements among the rest
 
 
@@ -161,6 +182,25 @@ def test_backward_matches_oracle_and_golden(name):
         assert err <= GRAD_REL_TOL or max_abs(g.cpu(), ref) <= 1e-7 + GRAD_ABS_ESCAPE * scale, (k, err, scale)
         n += 1
     assert n >= 20
+
+
+@pytest.fixture
+def kc_grid_3():
+    """persistent grid of 3 workgroups for every K-contiguous launch (C-ABI test hook): at 1,024 points x 512 columns = 16 tiles every
+    workgroup then walks several tiles and draws them from the pass's tile counters -- which the pass's FIRST kernel clears on the side
+    (encode forward, composite backward); the default grid gives every tile a workgroup of its own at this size"""
+    from snerf_amd import _lib
+    L = _lib.lib()
+    L.snerf_test_set_kc_grid(3)
+    yield 3
+    L.snerf_test_set_kc_grid(0)
+
+
+def test_full_width_pass_on_a_forced_small_grid(kc_grid_3):
+    """the in-pass clearing of the tile counters, pinned at a small size -- the whole forward + backward of the W = 512
+    reference fixture with three persistent workgroups per launch (the counters are LIVE: 16 tiles, 3 workgroups), against the same
+    reference outputs, losses and gradients as the default grid."""
+    test_full_width_forward_backward("sem_siren_full")
 
 
 @pytest.mark.parametrize("name", ["sem_siren_full", "satnerf_full_c1"])

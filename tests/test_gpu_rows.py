@@ -167,7 +167,7 @@ from snerf_amd.eval.utils.util import sharded_lean_inference
 from snerf_amd.eval.extract_pointcloud import extract_pointcloud
 pipe, rays, extras, ro = _frame_case()
 res = sharded_lean_inference(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, keys=("rgb_coarse", "depth_coarse", "semantic_label_coarse", "weights_coarse"), render_options=ro)
-pc = extract_pointcloud(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, render_options=ro)
+pc = extract_pointcloud(pipe.cfgs, pipe.renderer, pipe.models, rays, extras, render_options=ro, sharded=True)
 lo, hi = res.pop("_rows")
 assert (lo, hi) == parallel.frame_shard(rays.shape[0]) and res["weights_coarse"].shape[0] == hi - lo
 torch.save({{"res": {{k: v.cpu() for k, v in res.items()}}, "rows": (lo, hi), "pc": {{k: v.cpu() for k, v in pc.items()}}}}, {out!r} + str(rank))

@@ -231,11 +231,57 @@ def inference_case(name, cfg: O.OracleCfg, n_rays, seed):
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+def trajectory_case(name, cfg: O.OracleCfg, n_rays, seed, steps, final_params=("fc_net.8.weight",), car_prob=0.2):
+    """a16 + a18 composed over MANY steps: the reference's renderer, its loss modules under the gates of
+    semantic/components/training_step.py:22-92 and stock torch.optim.Adam(lr 5e-4, wd 0) (base_ray_pipeline.py:246-254) on ONE
+    fixed batch (epoch 0 of a config whose first_beta_epoch is 0, so a training loop that counts epochs itself sees the same gates).
+    Stored: the inputs, the total loss and every loss term BEFORE each of the `steps` optimiser steps and after the last one
+    (steps + 1 values), and the final values of `final_params` (+ the embedding).  Parameters regenerate from (cfg, seed)."""
+    torch.manual_seed(0)
+    cfgs, models, renderer, params = build_reference(cfg, seed)
+    b = O.synthetic_batch(n_rays, cfg.n_samples, seed=seed + 100, n_classes=max(cfg.n_classes, 2), car_prob=car_prob)
+    bt = O.batch_to_torch(b)
+    fix = {f"in_{k}": v for k, v in b.items()}
+    plist = [p for m in models.values() for p in m.parameters()]
+    opt = torch.optim.Adam(plist, lr=5e-4, weight_decay=0)
+    traj, terms = [], {}
+    for it in range(steps + 1):
+        opt.zero_grad()
+        r = render_with_u(renderer, models, bt["rays"], bt["extras"], bt["u"])
+        ld = losses_for_epoch(cfg, r, bt, 0)
+        l = sum(ld.values())
+        traj.append(l.item())
+        for k, v in ld.items():
+            terms.setdefault(k, []).append(v.item())
+        if it == steps:
+            break
+        l.backward()
+        opt.step()
+    fix["traj_total"] = np.array(traj, dtype=np.float64)
+    for k, v in terms.items():
+        fix[f"traj_{k}"] = np.array(v, dtype=np.float64)
+    named = dict(models["coarse"].named_parameters())
+    for k in final_params:
+        fix[f"final_{k}"] = named[k].detach().numpy().copy()
+    fix["final_model_t.weight"] = models["t"].weight.detach().numpy().copy()
+    meta = dict(name=name, seed=seed, epoch=0, n_rays=n_rays, steps=steps,
+                cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(cfg).items()},
+                torch=torch.__version__, reference="wagnva/semantic-nerf-for-satellite-data@2025-03-21")
+    fix["meta_json"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **fix)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, loss {traj[0]:.6f} -> {traj[-1]:.6f} over {steps} steps")
+
+
 FULL_GRADS_SEM = ("fc_net.0.weight", "fc_net.8.weight", "sun_v_net.0.weight", "semantic_prediction.2.weight", "model_t.weight")
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "--trajectories":   # only the round-5 additions (the other fixtures regenerate array-identically)
+        # I: long optimiser trajectories of the whole composed step -- 25 steps at W = 32 with L_t on, 10 steps at the full width
+        make_trajectories()
+        return
     small = dict(fc_units=32, n_samples=16, render_chunk_size=200)  # chunk < P: exercises the chunk loop
     # A: default semantic config at reduced width, beta loss active
     make_case("sem_siren_small", O.OracleCfg(**small), 48, seed=1, epoch=2, adam_steps=3)
@@ -264,6 +310,13 @@ def main():
     # H: seam-3 inference on explicit xyz/z_vals
     inference_case("inference_sem_small", O.OracleCfg(**small), 24, seed=10)
     inference_case("inference_satnerf_small", O.OracleCfg(model="satnerf", fc_units=32, n_samples=8), 24, seed=11)
+    make_trajectories()
+
+
+def make_trajectories():
+    small = dict(fc_units=32, n_samples=16, render_chunk_size=200)
+    trajectory_case("traj25_small", O.OracleCfg(first_beta_epoch=0, use_car_reg_loss=True, car_reg_loss_start=0, **small), 48, seed=12, steps=25)
+    trajectory_case("traj10_full", O.OracleCfg(first_beta_epoch=0), 16, seed=13, steps=10)
 
 
 if __name__ == "__main__":
