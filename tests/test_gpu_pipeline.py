@@ -78,7 +78,7 @@ def test_training_step_matches_reference_fixture(name, monkeypatch):
     assert set(terms) == set(ref), (sorted(terms), sorted(ref))
     for k, v in ref.items():
         assert abs(terms[k] - v) <= LOSS_RTOL * max(1.0, abs(v)), (k, terms[k], v)
-    assert abs(float(out["loss"]) - float(z["loss_total"])) <= LOSS_RTOL * max(1.0, abs(float(z["loss_total"])))
+    assert abs(float(out["loss"].detach()) - float(z["loss_total"])) <= LOSS_RTOL * max(1.0, abs(float(z["loss_total"])))
     out["loss"].backward()
     grads = {k: p.grad for k, p in pipe.model_coarse.named_parameters()}
     grads["model_t.weight"] = pipe.model_t.weight.grad
@@ -304,9 +304,11 @@ def _fixed_batch_loop(name, monkeypatch):
     return z, meta, pipe, loop, steps
 
 
-# loss bars: a0 * (1 + step) -- the optimiser amplifies the arithmetic's own noise from step to step; measured on MI355X (round 5,
-# printed by the test): traj25_small worst |dloss| per step / (1 + step), traj10_full likewise; bars = 10x those
-_TRAJ_BARS = {"traj25_small": (2e-5, 2e-3), "traj10_full": (1e-4, 5e-3)}
+# (loss bar a0, applied as a0 * (1 + step): the optimiser amplifies the arithmetic's own noise from step to step; final-weight bar,
+# relative L2).  Bars = ~10x what the test measured on MI355X in round 5 (it prints the numbers): traj25_small worst
+# |dloss| / (1 + step) 6.0e-8 (terms 1.7e-8), final fc_net.8.weight 4.0e-7 after moving by 6.0e-2; traj10_full 1.15e-6 (terms 1.3e-6),
+# weight 1.6e-6 after moving by 2.8e-2.  The one-plane mode (11-bit operands) would miss these bars by two orders of magnitude.
+_TRAJ_BARS = {"traj25_small": (1e-6, 5e-6), "traj10_full": (1.5e-5, 2e-5)}
 
 
 @pytest.mark.parametrize("name", ["traj25_small", "traj10_full"])
