@@ -101,6 +101,21 @@ __device__ __forceinline__ void join8(const u32x4 hi, const u32x4 lo, float inv_
   for (int i = 0; i < 8; ++i) x[i] = fmaf((float)h[i], inv_scale, (float)l[i] * inv_scale);   // two v_fma_mix_f32; exact (power of two)
 }
 
+// hi + lo as they lie (the value times 2^e, no scale applied): ONE mixed-precision FMA per element, exact
+__device__ __forceinline__ void sum8(const u32x4 hi, const u32x4 lo, float (&x)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(x[2 * i]) : "v"(hi[i]), "v"(lo[i]));
+    asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x[2 * i + 1]) : "v"(hi[i]), "v"(lo[i]));
+  }
+}
+// one plane as it lies: 8 fp16 -> fp32
+__device__ __forceinline__ void cvt8f(const u32x4 hi, float (&x)[8]) {
+  const f16x8 h = __builtin_bit_cast(f16x8, hi);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = (float)h[i];
+}
+
 // Row order inside a 32-row unit of a WF16 weight pack: MFMA row m of the unit holds matrix row (unit base) + wf16_row(m),
 // bits 2 and 3 of m exchanged (an involution).  The K-contiguous kernel uses the weights as the matrix cores' A operand,
 // so the accumulator of lane l holds, for ONE point (l & 31), the output columns m = (r & 3) + 8 (r >> 2) + 4 (l >> 5) of

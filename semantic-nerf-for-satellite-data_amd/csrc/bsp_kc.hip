@@ -16,13 +16,12 @@
 // registers.  (Round 2 computed C, moved every tile through an LDS strip and exchanged halves inside lane quads:
 // ~5 of its ~28 instructions per output element; the sine was another 16.)
 // Epilogues:
-//   ACT_SIN  sin(w0 (z + b)) in ONE pass over the accumulators.  The argument is formed in half-turns u = (w0 / pi)(z + b)
-//            by the same FMA that applies scale and bias; k = round(u) comes out of the mantissa of u + 1.5 * 2^23,
-//            f = u - k is exact, sin(pi f) is a degree-9 odd polynomial on [-1/2, 1/2], the sine's sign is bit 0 of k, and so
-//            is the sign of cos (cos(pi f) >= 0): the sign word of the derivative costs one v_alignbit per element.  The
-//            outputs lie in [-1, 1], so the block exponent is the constant 13 (as for the positional encoding): no block
-//            maximum, no second pass, no workgroup barrier.  Error: 2e-7 + 6e-8 |w0 z| (the rounding of u), the size of the
-//            reference's own fp32 rounding of w0 z.
+//   ACT_SIN  sin(w0 (z + b)) in ONE pass over the accumulators.  The argument is formed in revolutions x = (w0 / 2 pi)(z + b)
+//            by the same FMA that applies scale and bias and goes straight into v_sin_f32 (bsp_kc_epi.h: sin2pi8); the sign of
+//            cos is the parity of round(2 x), the low mantissa bit of 2 x + 1.5 * 2^23: one FMA and one v_alignbit per element
+//            for the sign word of the derivative.  The outputs lie in [-1, 1], so the block exponent is the constant 13 (as for
+//            the positional encoding): no block maximum, no second pass, no workgroup barrier.  Error: 2e-7 + 6e-8 |w0 z| (the
+//            rounding of x), the size of the reference's own fp32 rounding of w0 z.
 //   others   (plain / ReLU forward, derivative epilogues of the backward pass) two passes: values + block |max| (two waves
 //            share a 128-column exponent block: one exchange through LDS), then split into planes and store.
 #include "bsp_kc_epi.h"
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     if (lane + 64 >= nks) eBp = eB;
     if (lane >= nks) eAp = eA;
     if (wave == 0) { etab[lane] = eA; etab[lane + 64] = eB; }
-    if (BIAS) sbias[t] = bias_t * (ACT == ACT_SIN ? kargs()->w0 * INV_PI : 1.f);
+    if (BIAS) sbias[t] = bias_t * (ACT == ACT_SIN ? kargs()->w0 * INV_2PI : 1.f);
     const unsigned long long chg0 = __builtin_amdgcn_ballot_w64(eA != eAp), chg1 = __builtin_amdgcn_ballot_w64(eB != eBp);
 
     f32x16 acc[4][2];
@@ -456,8 +455,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     }
 
     if constexpr (ONEPASS) {
-      // ---- sine: one pass.  u = acc * (2^-e w0 / pi) + b w0 / pi (bias row staged in LDS, already scaled)
-      const float su = inv_in * e->w0 * INV_PI;
+      // ---- sine: one pass.  x = acc * (2^-e w0 / 2 pi) + b w0 / 2 pi in revolutions (bias row staged in LDS, already scaled)
+      const float su = inv_in * e->w0 * INV_2PI;
       const int c_tj = c_j0 >> 8;
       const int nd_n = NDOT > 0 ? e->nd_rows[c_tj] : 0;      // projections of this column tile (uniform)
       const float* snd = reinterpret_cast<const float*>(lds + KC_NDW) + (NDOT > 0 ? e->nd_woff[c_tj] : 0) + wj0 + 8 * lh;
@@ -486,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 #pragma unroll
               for (int c = 0; c < 8; ++c) v[c] = fmaf(acc[mi][nj][8 * gg + c], su, bj[gq][c]);
             }
-            sinpi8<SIGNS, SINM>(v, sw);
+            sin2pi8<SIGNS, SINM>(v, sw);
             if constexpr (NDOT > 0) {
 #pragma unroll
               for (int o = 0; o < NDOT; ++o)
@@ -580,8 +579,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       dma_h(0);
       dma_h(1);
       if constexpr (AUX != AUX_NONE) next_heads();   // (its 8 A pieces are younger than half-blocks 0, 1 and older than the later ones)
-      // derivative epilogues: the accumulator's scale and |w0| in one factor; the sign bits are xor-ed with w0's own sign
-      const unsigned w0mag = __float_as_uint(fabsf(e->w0) * inv_in);
+      // Derivative epilogues work on the RAW accumulators: every factor that is uniform over the wave's tile -- the accumulators'
+      // scale 2^-e_in, |w0|, the 2^-eH of the rebuilt cosine -- is one number `fac` that multiplies the column sums and the block
+      // maximum once and rides in the scale of the plane split; the sign bits are xor-ed with w0's own sign once per word.
+      // (Rows beyond I need no mask: their A rows were rejected, their accumulators are exactly 0 and every factor is finite.)
+      const float fac = AUX == AUX_SINREC ? inv_in * fabsf(e->w0) * inv_h : inv_in;
+      const int eHc = eH < -60 ? -60 : (eH > 60 ? 60 : eH);
+      const float one_s = pow2f(2 * eHc);                          // 1.0 in the units of s^2 (s = h 2^eH; eH = 13 for a SIREN layer's output)
       const unsigned sflip = e->w0 < 0.f ? 0xFFFFFFFFu : 0u;
       unsigned sword[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -592,7 +596,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
           const int hb = 4 * nj + mi;
-          const float okf = (32 * mi + pt) < nrows ? 1.f : 0.f;      // points beyond I: out of the maximum and the column sums
           u32x4 hh[2], hl[2];
           if (AUX != AUX_NONE) {
             // half-block hb (and everything older: the sign words) is home when all but the four pieces of hb + 1 are
@@ -604,13 +607,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
             for (int gg = 0; gg < 2; ++gg) {
               if constexpr (PL == 2) {
                 hh[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 128 + 16 * ((4 * gg + lh) ^ ((pt >> 1) & 7)));
-                hl[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 128 + 16 * ((4 * gg + 2 + lh) ^ ((pt >> 1) & 7)));
+                if (AUX == AUX_SINREC) hl[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 128 + 16 * ((4 * gg + 2 + lh) ^ ((pt >> 1) & 7)));
               } else {
                 hh[gg] = *reinterpret_cast<const u32x4*>(hreg + pt * 64 + 16 * ((2 * gg + lh) ^ ((pt >> 2) & 3)));
               }
             }
             if (hb + 2 < 8) {   // the buffer is free once these reads have returned
-              if constexpr (PL == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hl[0]), "+v"(hl[1]), "+v"(sword[mi])::"memory");
+              if constexpr (PL == 2 && AUX == AUX_SINREC) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(hl[0]), "+v"(hl[1]), "+v"(sword[mi])::"memory");
               else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[0]), "+v"(hh[1]), "+v"(sword[mi])::"memory");
               dma_h(hb + 2);
             }
@@ -622,37 +625,43 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
               const float x = acc[mi][nj][8 * gg + c];
-              v[c] = AUX == AUX_SINREC ? x : (BIAS ? fmaf(x, inv_in, bj[gq][c]) : x * inv_in);
+              v[c] = AUX != AUX_NONE || COLSUM ? x : (BIAS ? fmaf(x, inv_in, bj[gq][c]) : x * inv_in);
             }
             if (ACT == ACT_RELU) {
 #pragma unroll
               for (int c = 0; c < 8; ++c) v[c] = fmaxf(v[c], 0.f);
             }
-            if (AUX != AUX_NONE) {
-              float h[8];
-              if constexpr (PL == 2) join8(hh[gg], hl[gg], inv_h, h); else join8_1(hh[gg], inv_h, h);
-              if (AUX == AUX_SINREC) {
-                // w0 cos(w0 z) = +-|w0| sqrt(1 - h^2): the sign bit (xor-ed with w0's own sign, once per word) is shifted to
-                // bit 31 and merged over |w0| 2^-e by one v_bfi; 1 - h^2 is clamped at 0 by the FMA's output modifier
+            if (AUX == AUX_SINREC) {
+              // w0 cos(w0 z) = +-|w0| sqrt(1 - h^2), from the planes as they lie: s = hi + lo = h 2^eH (one mixed-precision FMA,
+              // exact), 2^2eH - s^2 (one FMA; >= 0 for |h| <= 1, |.| on the root's operand covers a stray ulp), the root, and the
+              // sign bit shifted to bit 31 and merged over the root by one v_bfi
+              float sv[8];
+              if constexpr (PL == 2) sum8(hh[gg], hl[gg], sv); else cvt8f(hh[gg], sv);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                  float om;
-                  asm("v_fma_f32 %0, -%1, %1, 1.0 clamp" : "=v"(om) : "v"(h[c]));
-                  unsigned w0s_bits;
-                  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(w0s_bits) : "s"(0x7fffffffu), "v"(w0mag), "v"(sword[mi] << (31 - (16 * nj + 8 * gg + c))));
-                  v[c] *= __uint_as_float(w0s_bits) * __builtin_amdgcn_sqrtf(om);
-                }
-              } else {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = h[c] > 0.f ? v[c] : 0.f;
+              for (int c = 0; c < 8; ++c) {
+                const float om = fmaf(-sv[c], sv[c], one_s);
+                const float root = __builtin_amdgcn_sqrtf(fabsf(om));
+                // (plain C, not an asm v_bfi: the consumer of a transcendental's result needs a wait state the compiler only inserts
+                //  for instructions it can see -- an asm statement here read stale roots in half of the rows)
+                const unsigned rs = __float_as_uint(root) | ((sword[mi] << (31 - (16 * nj + 8 * gg + c))) & 0x80000000u);   // root >= 0: one v_and_or
+                v[c] *= __uint_as_float(rs);
               }
+            } else if (AUX == AUX_RELU_MASK) {
+              // h > 0 <=> its hi plane > 0 (hi = 0 only where the value rounds to 0 on the plane's grid, and lo is 0 with it)
+              float hv[8];
+              cvt8f(hh[gg], hv);
+#pragma unroll
+              for (int c = 0; c < 8; ++c) v[c] = hv[c] > 0.f ? v[c] : 0.f;
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-              if (COLSUM) cs[8 * gg + c] = fmaf(v[c], okf, cs[8 * gg + c]);
+              if (COLSUM) cs[8 * gg + c] += v[c];
               acc[mi][nj][8 * gg + c] = v[c];
             }
-            if (jw + 16 * gq < e->J) wmax = fmaxf(wmax, okf * absmax3(v[6], v[7], absmax3(v[4], v[5], absmax3(v[2], v[3], absmax3(v[0], v[1], 0.f)))));
+            if (jw + 16 * gq < e->J) {
+              const float m8 = absmax3(v[6], v[7], absmax3(v[4], v[5], absmax3(v[2], v[3], absmax3(v[0], v[1], 0.f))));
+              wmax = fmaxf(wmax, (BIAS && (32 * mi + pt) >= nrows) ? 0.f : m8);   // (forward launches add the bias to rows beyond I too: out of the maximum)
+            }
           }
         }
         if (COLSUM && e->colsum != nullptr) {   // one partial row per 128-point tile
@@ -663,20 +672,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
             for (int gg = 0; gg < 2; ++gg)
               if (jw + 16 * (2 * nj + gg) < e->J) {
                 float* d = e->colsum + (size_t)c_ti * e->ldcs + jw + 16 * (2 * nj + gg) + 8 * lh;
-                *reinterpret_cast<float4*>(d) = make_float4(cs[8 * gg], cs[8 * gg + 1], cs[8 * gg + 2], cs[8 * gg + 3]);
-                *reinterpret_cast<float4*>(d + 4) = make_float4(cs[8 * gg + 4], cs[8 * gg + 5], cs[8 * gg + 6], cs[8 * gg + 7]);
+                *reinterpret_cast<float4*>(d) = make_float4(cs[8 * gg] * fac, cs[8 * gg + 1] * fac, cs[8 * gg + 2] * fac, cs[8 * gg + 3] * fac);
+                *reinterpret_cast<float4*>(d + 4) = make_float4(cs[8 * gg + 4] * fac, cs[8 * gg + 5] * fac, cs[8 * gg + 6] * fac, cs[8 * gg + 7] * fac);
               }
           }
         }
       }
       // block maximum: waves 2 c and 2 c + 1 share the exponent block (ti, column block c of the tile)
-      wmax = wave_max(wmax);
+      constexpr bool RAW = AUX != AUX_NONE || COLSUM;          // the accumulators hold raw values: true value = raw * fac
+      wmax = wave_max(wmax) * (RAW ? fac : 1.f);
       if (el == 0) smax[wave] = wmax;
       barrier_raw();     // (not __syncthreads(): that drains the vector-memory counter too, behind the next tile's requests and this tile's
                          //  stores) also: every wave has finished with the stored-activation buffers the strips share
       const float bmax = fmaxf(smax[wave & 2], smax[(wave & 2) + 1]);
       const int eC = exp_of_maxbits(__float_as_uint(bmax));
-      const float sc = pow2f(eC);
+      const float sc = pow2f(eC) * (RAW ? fac : 1.f);
       if ((wave & 1) == 0 && el == 0 && wave_cols) e->EC[(size_t)c_ti * ncb_of(e->ldc) + ((e->c_col0 + jw) >> 7)] = eC;
       if (more) headW();     // the registers of pass A are free: the next tile's first weight fragments go out ahead of the stores
       // ---- pass B: split, through the strip, store
@@ -722,7 +732,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
 int prof_hook_begin(double flops, int variant, hipStream_t st);   // gemm.hip: per-launch HIP events when profiling is on
 void prof_hook_end(int token, hipStream_t st);
 int check_kc(const KcArgs& a, bool narrow);                        // bsp_gemm.hip
-static int sin_mode() { return SIN_HW; }   // v_sin_f32 on the reduced argument; SIN_POLY (degree-9 polynomial) is the test-only alternative of tools/ablate
 
 // workgroup slots of the device: two 256-thread workgroups per CU (registers, LDS).  snerf_test_set_kc_grid (test hook of the
 // C-ABI) forces a small grid so that small problems exercise the tile loop and the tile counters.
@@ -772,20 +781,19 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   const bool cs = a.colsum != nullptr;
 #define KC_LAUNCH(ACT_, AUX_, CS_, SG_, SM_) do { if (a.pl == 2) hipLaunchKernelGGL((gemm_kc_kernel<2, ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a); \
                                                  else hipLaunchKernelGGL((gemm_kc_kernel<1, ACT_, AUX_, CS_, SG_, SM_, DIAG>), grid, block, 0, st, a); } while (0)
-#define KC_LAUNCH_ND(SG_, ND_) do { if (a.pl == 2) hipLaunchKernelGGL((gemm_kc_kernel<2, ACT_SIN, AUX_NONE, false, SG_, SIN_HW, DIAG, ND_>), grid, block, 0, st, a); \
-                                    else hipLaunchKernelGGL((gemm_kc_kernel<1, ACT_SIN, AUX_NONE, false, SG_, SIN_HW, DIAG, ND_>), grid, block, 0, st, a); } while (0)
-  if (a.aux_mode == AUX_SINREC) KC_LAUNCH(ACT_NONE, AUX_SINREC, true, false, SIN_POLY);
-  else if (a.aux_mode == AUX_RELU_MASK) KC_LAUNCH(ACT_NONE, AUX_RELU_MASK, true, false, SIN_POLY);
+#define KC_LAUNCH_ND(SG_, ND_) do { if (a.pl == 2) hipLaunchKernelGGL((gemm_kc_kernel<2, ACT_SIN, AUX_NONE, false, SG_, SIN_DIRECT, DIAG, ND_>), grid, block, 0, st, a); \
+                                    else hipLaunchKernelGGL((gemm_kc_kernel<1, ACT_SIN, AUX_NONE, false, SG_, SIN_DIRECT, DIAG, ND_>), grid, block, 0, st, a); } while (0)
+  if (a.aux_mode == AUX_SINREC) KC_LAUNCH(ACT_NONE, AUX_SINREC, true, false, SIN_FRACT);
+  else if (a.aux_mode == AUX_RELU_MASK) KC_LAUNCH(ACT_NONE, AUX_RELU_MASK, true, false, SIN_FRACT);
   else if (a.act == ACT_SIN) {
-    const bool hw = sin_mode() == SIN_HW;
     if (a.nd_w != nullptr && a.nd_omax == 1) { if (a.Csign == nullptr) KC_LAUNCH_ND(false, 1); else KC_LAUNCH_ND(true, 1); }
     else if (a.nd_w != nullptr) { if (a.Csign == nullptr) KC_LAUNCH_ND(false, 5); else KC_LAUNCH_ND(true, 5); }
-    else if (a.Csign == nullptr) { if (hw) KC_LAUNCH(ACT_SIN, AUX_NONE, false, false, SIN_HW); else KC_LAUNCH(ACT_SIN, AUX_NONE, false, false, SIN_POLY); }
-    else { if (hw) KC_LAUNCH(ACT_SIN, AUX_NONE, false, true, SIN_HW); else KC_LAUNCH(ACT_SIN, AUX_NONE, false, true, SIN_POLY); }
+    else if (a.Csign == nullptr) KC_LAUNCH(ACT_SIN, AUX_NONE, false, false, SIN_DIRECT);
+    else KC_LAUNCH(ACT_SIN, AUX_NONE, false, true, SIN_DIRECT);
   }
-  else if (a.act == ACT_RELU) KC_LAUNCH(ACT_RELU, AUX_NONE, false, false, SIN_POLY);
-  else if (cs) KC_LAUNCH(ACT_NONE, AUX_NONE, true, false, SIN_POLY);
-  else KC_LAUNCH(ACT_NONE, AUX_NONE, false, false, SIN_POLY);
+  else if (a.act == ACT_RELU) KC_LAUNCH(ACT_RELU, AUX_NONE, false, false, SIN_FRACT);
+  else if (cs) KC_LAUNCH(ACT_NONE, AUX_NONE, true, false, SIN_FRACT);
+  else KC_LAUNCH(ACT_NONE, AUX_NONE, false, false, SIN_FRACT);
 #undef KC_LAUNCH
 #undef KC_LAUNCH_ND
   SNERF_LAUNCH_CHECK();

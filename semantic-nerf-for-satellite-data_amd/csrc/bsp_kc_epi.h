@@ -5,37 +5,33 @@
 namespace snerf {
 namespace bsp {
 
-constexpr float INV_PI = 0.31830988618379067154f;
 constexpr unsigned OOBH = 0x80000000u;           // rejected voffset that survives the addition of an instruction offset
 
-constexpr int SIN_POLY = 0, SIN_HW = 1;
+constexpr float INV_2PI = 0.15915494309189533577f;
 
-// sin(pi u_c) in place for eight values.  SIGNS: bit "cos(pi u_c) < 0" (= parity of round(u_c)) enters `sw` from the top,
+// sin(2 pi x_c) in place for eight values x_c in REVOLUTIONS (the FMA that applies scale and bias forms them), by v_sin_f32 on the
+// unreduced argument: inside the instruction's domain (|x| <= 256 revolutions) its own range reduction is exact -- measured on
+// gfx950 against fp64, bit for bit the results of v_sin_f32(v_fract_f32(x)) (tools/ablate/vsin_range.hip) -- and a SIREN
+// pre-activation of |w0 z| <= 1,608 rad lies inside it; KcArgs::sin_wide (host: |w0| > 30) keeps the explicit v_fract_f32 for
+// layers that may leave it.
+// SIGNS: bit "cos(2 pi x_c) < 0" (= parity of round(2 x_c), the low mantissa bit of 2 x_c + 1.5 * 2^23) enters `sw` from the top,
 // earlier bits move down (after 32 calls' worth the first element sits in bit 0).
+constexpr int SIN_FRACT = 0, SIN_DIRECT = 1;
 template <bool SIGNS, int SINM>
-__device__ __forceinline__ void sinpi8(float (&u)[8], unsigned& sw) {
+__device__ __forceinline__ void sin2pi8(float (&x)[8], unsigned& sw) {
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    const float t = u[c] + 12582912.f;                 // low mantissa bits = k = round(u)
-    const unsigned tb = __float_as_uint(t);
-    float s;
-    if (SINM == SIN_HW) {
-      float fr;
-      asm("v_fract_f32 %0, %1" : "=v"(fr) : "v"(0.5f * u[c]));
-      asm("v_sin_f32 %0, %1" : "=v"(s) : "v"(fr));
-    } else {
-      const float kf = t - 12582912.f;
-      const float f = u[c] - kf;                       // exact, |f| <= 1/2
-      const float f2 = f * f;
-      float q = fmaf(f2, 0.077218386155008978f, -0.59804419391100816f);
-      q = fmaf(q, f2, 2.5500311935191413f);
-      q = fmaf(q, f2, -5.1677068661679284f);
-      q = fmaf(q, f2, 3.1415925798055815f);
-      s = __uint_as_float((tb << 31) + __float_as_uint(f * q));   // (-1)^k: one v_lshl_add
+    if (SIGNS) {
+      const float t = fmaf(x[c], 2.f, 12582912.f);       // low mantissa bit = parity of k = round(2 x)
+      sw = __builtin_amdgcn_alignbit(__float_as_uint(t), sw, 1);
     }
-    u[c] = s;
-    if (SIGNS) sw = __builtin_amdgcn_alignbit(tb, sw, 1);
+    x[c] = __builtin_amdgcn_sinf(SINM == SIN_FRACT ? __builtin_amdgcn_fractf(x[c]) : x[c]);
   }
+  // gfx940+: a VALU instruction may not read a transcendental's result in the very next issue slot.  The compiler pads the readers
+  // it can see; the plane split that consumes these values is made of asm statements (bsp.h: split8 / cvt8), which it cannot.  One
+  // wait state behind the eight sines, tied to all eight values, keeps every reader -- asm or not -- at least one slot away
+  // (tools/check_vgpr_hazards.py scan 3 holds the generated code to it).
+  asm volatile("s_nop 0" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
 }
 
 // sum over the 32 lanes that share l >> 5 (DPP adds inside the 16-lane rows, row_bcast15 across the pair of rows); valid in

@@ -53,7 +53,8 @@ def device_asm(tmp_path_factory):
 
 
 def test_no_vgpr_hazards_in_any_kernel(device_asm):
-    """tools/check_vgpr_hazards.py over the whole library: no VALU write into the data registers of a wide store within two wait
+    """tools/check_vgpr_hazards.py over the whole library (scan 3, round 5: no VALU instruction reads a transcendental's result in
+    the next issue slot -- an asm v_bfi behind a v_sqrt did, and half of the derivative epilogue's rows were wrong): no VALU write into the data registers of a wide store within two wait
     states (the round-4 corruption: csrc/bsp_dev.h store_data_guard), no ds_read returning into the data registers of an unretired
     wide ds_write (the round-2 one: csrc/bsp_kc.hip keep_planes).  Neither is interlocked by the hardware or known to the compiler;
     both came and went with register allocation, i.e. with unrelated edits -- hence a check on the generated code."""
@@ -68,6 +69,8 @@ def test_no_vgpr_hazards_in_any_kernel(device_asm):
         assert not hits, f"{name}.hip: store data overwritten too early: {hits[:3]}"
         hits = chk.scan_lds(lines)
         assert not hits, f"{name}.hip: ds_read into unretired ds_write data: {hits[:3]}"
+        hits = chk.scan_trans(lines)
+        assert not hits, f"{name}.hip: a VALU instruction reads a transcendental's result without a wait state: {hits[:3]}"
     assert n_store > 100       # the scan saw the plane stores at all
     # the scanner does flag the pattern it was written for
     bad = ["_Zk:", "buffer_store_dwordx4 v[90:93], v122, s[36:39], s20 offen nt", "v_or_b32_e32 v90, 32, v182", "s_endpgm"]
@@ -76,6 +79,10 @@ def test_no_vgpr_hazards_in_any_kernel(device_asm):
     assert not chk.scan_store(ok)
     bad = ["_Zk:", "ds_write_b128 v1, v[4:7]", "ds_read_b128 v[6:9], v2", "s_waitcnt lgkmcnt(0)", "s_endpgm"]
     assert len(chk.scan_lds(bad)) == 1
+    bad = ["_Zk:", "v_sqrt_f32_e64 v7, |v3|", "v_bfi_b32 v9, s4, v7, v8", "s_endpgm"]       # the round-5 corruption
+    assert len(chk.scan_trans(bad)) == 1
+    ok = ["_Zk:", "v_sqrt_f32_e64 v7, |v3|", "s_nop 0", "v_bfi_b32 v9, s4, v7, v8", "v_sin_f32_e32 v1, v2", "v_sqrt_f32_e32 v3, v1", "s_endpgm"]
+    assert not chk.scan_trans(ok)
 
 
 def test_tile_counter_atomic_result_is_untouched_until_its_wait(device_asm):

@@ -11,6 +11,12 @@ interlocks nor LLVM's hazard recognizer covers:
    ds_write_b64/b96/b128 that no s_waitcnt lgkmcnt has retired yet (LDS operations retire in order; scalar loads share the counter
    and return out of order, so a counted wait only retires LDS operations when no scalar load is outstanding).
 
+3. transcendental forwarding (round 5; gfx940+): a VALU instruction that reads the result of a transcendental (v_sin / v_cos / v_sqrt /
+   v_rsq / v_rcp / v_exp / v_log) needs one wait state behind it.  LLVM inserts the s_nop for instructions it can see; an asm statement
+   on either side is opaque to it -- an asm v_bfi right behind a compiler-generated v_sqrt read stale roots in half of the rows of the
+   derivative epilogue.  Flagged: a non-transcendental VALU instruction that names the destination of the transcendental issued
+   immediately before it.
+
 The walk is linear per function (branches ignored; scan 2 walks each function twice to cover loop back-edges).
 
 Usage: python tools/check_vgpr_hazards.py file.s [more.s]   -> exit status 1 if anything is flagged
@@ -123,6 +129,38 @@ def scan_store(lines, need=NEED_WAIT_STATES):
     return out
 
 
+TRANS = re.compile(r"v_(sin|cos|sqrt|rsq|rcp|rcp_iflag|exp|log)_(f32|f16|f64)")
+
+
+def scan_trans(lines):
+    """-> list of (function, trans line no, trans text, reader line no, reader text)"""
+    fn, prev, out = None, None, []
+    for no, ln in enumerate(lines, 1):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            fn, prev = m.group(1), None
+        t = ln.split(";")[0].strip()
+        if not t or t.startswith("."):
+            continue
+        if t.endswith(":"):
+            prev = None           # a label: the predecessor in issue order is not known (a branch costs more than a wait state)
+            continue
+        op = t.split()[0]
+        if prev is not None and op.startswith("v_") and not TRANS.match(op):
+            srcs = t[len(op):].split(",")[1:]
+            used = set()
+            for a in srcs:
+                for tok in re.findall(r"v\[\d+:\d+\]|v\d+", a):
+                    used |= regs(tok)
+            if used & prev[2]:
+                out.append((fn, prev[0], prev[1], no, t))
+        if TRANS.match(op):
+            prev = (no, t, regs(t[len(op):].split(",")[0].split()[0]))
+        else:
+            prev = None
+    return out
+
+
 if __name__ == "__main__":
     bad = 0
     for f in sys.argv[1:]:
@@ -132,6 +170,9 @@ if __name__ == "__main__":
             bad += 1
         for fn, rno, rt, wno, wt in scan_lds(lines):
             print(f"{f}:{rno}: {rt}\n    returns into the data registers of line {wno}: {wt}\n    in {fn}")
+            bad += 1
+        for fn, tno, tt, rno, rt in scan_trans(lines):
+            print(f"{f}:{rno}: {rt}\n    reads the result of the transcendental right before it (line {tno}: {tt})\n    in {fn}")
             bad += 1
     print(f"{bad} hazard(s)")
     sys.exit(1 if bad else 0)
