@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SNERF_ABI_VERSION 4
+#define SNERF_ABI_VERSION 5
 #define SNERF_MAX_LAYERS 16
 
 /* error codes */
@@ -281,6 +281,8 @@ int snerf_profile_end(SnerfProfile* out);
 /* test hooks of the block-scaled fp16-plane kernels (csrc/bsp.h): fp32 in / fp32 out around one launch; `planes` = 2 (default
  * arithmetic) or 1 (SNERF_FLAG_F16X1); synchronous and allocating -- tests only */
 int snerf_test_set_kc_grid(int n_workgroups);   /* persistent grid of the K-contiguous launches (0: two per CU): forces the tile loop at test sizes */
+int snerf_test_set_trunk_fusion(int on);        /* 0: launch-per-layer trunk for every pass; 1 (default): one-plane passes of the W = 512 SIREN model
+                                                 * run the trunk as ONE persistent launch (csrc/bsp_trunk.hip) */
 int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int col0, float* dst, int* exps_out, int planes, void* stream);
 int snerf_test_bsp_kc(const float* A, const float* A2, int Ka, const float* W, const float* bias, int I, int J, int K, int a_col0,
                       int c_col0, int act, float w0, int aux_mode, const float* Hact, const unsigned* Hsign, float* C,

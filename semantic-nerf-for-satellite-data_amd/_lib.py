@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SNERF_LIB_PATH: an alternative build of the library (ablation harness of tools/ablate; diagnostics only)
 LIB_PATH = os.environ.get("SNERF_LIB_PATH") or os.path.join(_HERE, "libsnerf_hip.so")
 MAX_LAYERS = 16
-ABI_VERSION = 4   # include/snerf_hip.h SNERF_ABI_VERSION
+ABI_VERSION = 5   # include/snerf_hip.h SNERF_ABI_VERSION
 
 FLAG_TRAIN = 1
 FLAG_SC_PASS = 2
@@ -127,6 +127,8 @@ def lib():
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.snerf_test_set_kc_grid.restype = C.c_int
     L.snerf_test_set_kc_grid.argtypes = [C.c_int]
+    L.snerf_test_set_trunk_fusion.restype = C.c_int
+    L.snerf_test_set_trunk_fusion.argtypes = [C.c_int]
     L.snerf_test_bsp_roundtrip.restype = C.c_int
     L.snerf_test_bsp_roundtrip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.snerf_test_bsp_kc.restype = C.c_int
@@ -171,4 +173,4 @@ EXPORTED_SYMBOLS = ("snerf_version", "snerf_last_error", "snerf_packed_floats", 
                     "snerf_pack_params", "snerf_unpack_grads", "snerf_forward", "snerf_backward",
                     "snerf_loss_workspace_bytes", "snerf_loss_partial", "snerf_loss_finish", "snerf_profile_begin",
                     "snerf_profile_end", "snerf_sample_z", "snerf_adam_step", "snerf_test_bsp_roundtrip", "snerf_test_bsp_kc",
-                    "snerf_test_bsp_dw", "snerf_test_set_kc_grid", "snerf_embedding_rows", "snerf_embedding_backward")
+                    "snerf_test_bsp_dw", "snerf_test_set_kc_grid", "snerf_test_set_trunk_fusion", "snerf_embedding_rows", "snerf_embedding_backward")

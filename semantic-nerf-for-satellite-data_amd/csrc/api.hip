@@ -98,6 +98,12 @@ static void plan_bsp(Plan& p) {
   p.nd_sig = p.siren && p.W % 256 == 0 && p.W <= 1024;
   p.nd_sun = p.siren && p.H % 256 == 0 && p.H <= 1024;
   p.nd_fin = !p.sc && p.siren && p.H == 256 && p.C <= ND_FIN;   // one 256-column tile per head block, at most ND_FIN outputs per block
+  {  // bsp_trunk.hip: the shapes it is written for (launch_trunk checks them again)
+    bool ok = p.pl == 1 && p.siren && p.nd_sig && p.W == 512 && p.Ep == 64 && p.L >= 3 && p.L <= bsp::TR_MAXL &&
+              !(p.skip_mask & 1u) && (p.skip_mask >> (p.L - 1)) == 0u;
+    for (int i = 0; ok && i < p.L; ++i) ok = p.k_tr[i] == (i == 0 ? 64 : (((p.skip_mask >> i) & 1u) ? 576 : 512));
+    p.fuse_trunk = ok;
+  }
   if (p.nd_sig) p.o_sigpart = wtake((size_t)4 * (p.W / 256) * Pp * 4); else p.o_sigo = wtake(Pp * NARROW * 4);
   if (p.nd_sun) p.o_sunpart = wtake((size_t)4 * (p.H / 256) * Pp * 4); else p.o_suno = wtake(Pp * NARROW * 4);
   if (p.nd_fin) p.o_finpart = wtake((size_t)4 * (p.KF / 256) * ND_FIN * Pp * 4); else if (!p.sc) p.o_fino = wtake(Pp * NARROW * 4);
@@ -402,7 +408,9 @@ int snerf_test_bsp_roundtrip(const float* src, int rows, int cols, int ld, int c
 
 // persistent grid of the K-contiguous launches: n workgroups instead of two per CU (0: default) -- small test problems then walk
 // several tiles per workgroup and draw them from the tile counters
-int snerf_test_set_kc_grid(int n) { bsp::kc_set_grid_override(n); return SNERF_OK; }
+int snerf_test_set_kc_grid(int n) { bsp::kc_set_grid_override(n); bsp::trunk_set_grid_override(n); return SNERF_OK; }
+// 0: every pass takes the launch-per-layer path (the fused trunk of bsp_trunk.hip is compared with it bit for bit); 1: default
+int snerf_test_set_trunk_fusion(int on) { bsp::trunk_set_fusion(on); return SNERF_OK; }
 
 // C[I][J] = epilogue(A[I][Ka] | A2[I][K-Ka]) . W[J][K]^T).  The A tensors are placed at column a_col0 of wider plane
 // tensors and the output at column c_col0 (exercises the column-offset / exponent-block arithmetic).

@@ -176,6 +176,23 @@ struct DwArgs {
   int pl = 2;                        // planes of A and B
 };
 
+// ---- the SIREN trunk as one persistent launch (bsp_trunk.hip; one plane, W = 512, gamma of 64 columns) -----------------------------
+constexpr int TR_MAXL = 8;
+struct TrunkArgs {
+  const char* pe = nullptr; const int* Epe = nullptr;       // gamma(x): one-plane tensor [P][64] + its exponent per 128 points
+  int P = 0, W = 0, L = 0; unsigned skip_mask = 0;
+  int gamma_free_layer = 0;                                  // filled by launch_trunk: the last layer that reads gamma (>= 2)
+  const char* Wp[TR_MAXL] = {}; const int* EW[TR_MAXL] = {}; unsigned w_bytes[TR_MAXL] = {}; int K[TR_MAXL] = {};   // WF16 packs (one plane), K: 64 | 512 | 576
+  const float* bias[TR_MAXL] = {}; float w0[TR_MAXL] = {};
+  char* H[TR_MAXL] = {}; int* EH[TR_MAXL] = {}; unsigned* Hsign[TR_MAXL] = {};   // outputs [P][W] one plane: the last layer always, every layer when training
+  const float* nd_w = nullptr; float* nd_out = nullptr; unsigned long long nd_stride = 0;   // sigma's projection: 8 partial sums per point
+  int* tile_ctr = nullptr;                                   // 8 zeroed ints
+};
+int launch_trunk(const TrunkArgs& a, bool train, hipStream_t st);
+void trunk_set_grid_override(int n);                       // test hook: persistent grid of n workgroups (0: one per CU)
+void trunk_set_fusion(int on);                             // test hook: 0 = the launch-per-layer path for every pass
+bool trunk_fusion_enabled();
+
 int launch_kc(const KcArgs& a, hipStream_t st);          // 128 x 256 tiles, BSP output
 void kc_set_grid_override(int n);                          // test hook: persistent grid of n workgroups (0: two per CU)
 int launch_kc_narrow(const KcArgs& a, hipStream_t st);   // 128 x 32 tiles, fp32 output (Cf), bias only

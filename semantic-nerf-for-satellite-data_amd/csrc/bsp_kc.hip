@@ -42,8 +42,9 @@ constexpr int KC_NDW = KC_HSIGN;                 // NDOT launches (forward only:
 constexpr int KC_NDW_FLOATS = 2560;              // 10 KiB: e.g. (3 + 5 + 1 + 1) rows of 256 columns (the final head layers), or one row of <= 1024
 constexpr int KC_LDS_ND = KC_NDW + 4 * KC_NDW_FLOATS;
 // DIAG (tools/ablate/build_diag.sh only; the product instantiates DIAG = false): KcArgs::dbg removes operand traffic through
-// zero-size descriptors -- 1: A, 2: W (host side), 4: stores, 8: every tile reads the first 128 rows of A (always L2-resident).
-// Timing-only: the results are wrong.
+// zero-size descriptors -- 1: A, 2: W (host side), 4: stores, 8: every tile reads the first 128 rows of A (always L2-resident);
+// 16: the epilogue's arithmetic, strips and stores are skipped (tile bookkeeping and next-tile requests stay), 32: no workgroup barrier
+// inside the k-loop, 64: no fragment reads inside the k-loop.  Timing-only: the results are wrong.
 // PL = planes per operand / result tensor (bsp.h).  PL = 1: a 16-column group is 32 bytes, so the SAME bytes carry twice the
 // contraction depth -- a "sub-step" below is 64 bytes of every A row = 16 k of two planes (3 products) or 32 k of one plane
 // (1 product per 16 k): same LDS traffic, same request counts, 16 instead of 24 MFMAs per sub-step; a stage (128 bytes per row)
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
   const int nst = (nks + 1) >> 1, nst1 = nks1 >> 1;          // stages; stages of the first segment (Ka % 32 == 0 if two)
   constexpr bool ONEPASS = ACT == ACT_SIN;                   // outputs in [-1, 1]: constant block exponent
   constexpr bool BIAS = AUX == AUX_NONE && !COLSUM;           // forward launches; the backward ones (column sums) have none
+  const int dbg = DIAG ? p->dbg : 0;
 
   // ---- per-lane constants (the same for every tile of this workgroup) --------------------------------------------------
   // A: a stage is 32 k deep = 128 rows x 128 B (two column groups, the tensor's own byte order); its sixteen 1 KiB pieces
@@ -308,19 +310,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
           acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.l[mi], acc[mi][0], 0, 0, 0);
           acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.l[mi], acc[mi][1], 0, 0, 0);
         }
-        if (mi == 0 && u == 1) { __builtin_amdgcn_sched_barrier(0); barrier_raw(); __builtin_amdgcn_sched_barrier(0); }
+        if (mi == 0 && u == 1 && !(DIAG && (dbg & 32))) { __builtin_amdgcn_sched_barrier(0); barrier_raw(); __builtin_amdgcn_sched_barrier(0); }
+        const bool rd = !(DIAG && (dbg & 64));
         if constexpr (PL == 2) {
-          const f16x8 nl = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
+          const f16x8 nl = rd ? ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]) : fa.l[mi];
           acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.h[mi], acc[mi][0], 0, 0, 0);
           acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.h[mi], acc[mi][1], 0, 0, 0);
           fa.l[mi] = nl;
-          fa.h[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);
+          if (rd) fa.h[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);
         } else {
-          const f16x8 nh = ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);   // fa.h[mi] has issued its last MFMA
+          const f16x8 nh = rd ? ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]) : fa.h[mi];   // fa.h[mi] has issued its last MFMA
           acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, fa.l[mi], acc[mi][0], 0, 0, 0);
           acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, fa.l[mi], acc[mi][1], 0, 0, 0);
           fa.h[mi] = nh;
-          fa.l[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
+          if (rd) fa.l[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the blocks apart: left alone, the scheduler gathers the reads at the end
       }
@@ -454,7 +457,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       }
     }
 
-    if constexpr (ONEPASS) {
+    if (DIAG && (dbg & 16)) {
+      // (diagnostic: no epilogue work at all; the accumulators are consumed so that the k-loop stays)
+      float keep = 0.f;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < 2; ++nj) keep += acc[mi][nj][0];
+      if (keep == 12345.678f) smax[wave] = keep;
+      if constexpr (AUX != AUX_NONE) next_heads();
+      if (!ONEPASS && more) headW();
+    } else if constexpr (ONEPASS) {
       // ---- sine: one pass.  x = acc * (2^-e w0 / 2 pi) + b w0 / 2 pi in revolutions (bias row staged in LDS, already scaled)
       const float su = inv_in * e->w0 * INV_2PI;
       const int c_tj = c_j0 >> 8;

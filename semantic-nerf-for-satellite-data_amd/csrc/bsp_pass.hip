@@ -71,7 +71,29 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
     RC(bsp::launch_zero_cols(ws.c(p.o_fa) + (size_t)W * EB, (size_t)p.FA * EB, (size_t)(p.Wf - W) * EB, P, st));
   // 3. trunk (rs_semantic.py:325-334)
   const int act = p.siren ? ACT_SIN : ACT_RELU;
-  for (int i = 0; i < p.L; ++i) {
+  const bool fused = p.fuse_trunk && bsp::trunk_fusion_enabled();
+  if (fused) {   // one persistent launch, the activation tile resident in LDS (bsp_trunk.hip); inference: only the last layer's planes + sigma's partials leave
+    bsp::TrunkArgs g;
+    g.pe = ws.c(p.o_pe); g.Epe = ws.i(p.e_pe); g.P = P; g.W = W; g.L = p.L; g.skip_mask = p.skip_mask;
+    const char* planes = reinterpret_cast<const char*>(pk + p.n_fp32);
+    for (int i = 0; i < p.L; ++i) {
+      const int job = p.wj_tr[i];
+      g.Wp[i] = planes + p.wj_off[job];
+      g.EW[i] = reinterpret_cast<const int*>(planes + p.wp_bytes) + p.wj_e[job];
+      g.w_bytes[i] = (unsigned)bsp::wp16_bytes(p.wj_rows[job], p.wj_K[job], 1);
+      g.K[i] = p.k_tr[i];
+      g.bias[i] = pk + p.b_tr[i];
+      g.w0[i] = i == 0 ? 30.f : 1.f;
+    }
+    for (int i = p.train ? 0 : p.L - 1; i < p.L; ++i) {   // the layers whose planes leave: all of them for the backward pass, else the last
+      g.H[i] = ws.c(p.o_h[i]); g.EH[i] = ws.i(p.e_h[i]);
+      if (p.train) g.Hsign[i] = ws.u(p.o_c[i]);
+    }
+    g.nd_w = pk + p.w_fs + (size_t)W * W; g.nd_out = ws.f(p.o_sigpart); g.nd_stride = p.Pp;
+    g.tile_ctr = ws.i(p.o_kcq) + 16 * kcq++;
+    RC(bsp::launch_trunk(g, p.train, st));
+  }
+  for (int i = 0; i < p.L && !fused; ++i) {
     bsp::KcArgs g;
     const bool skip = (p.skip_mask >> i) & 1u;
     if (i == 0) { g.A = ws.c(p.o_pe); g.EA = ws.i(p.e_pe); g.lda = p.Ep; g.Ka = p.Ep; }

@@ -55,6 +55,9 @@ struct Plan {
   // [4 * (W / 256)][Pp] and [4 * (H / 256)][Pp] floats; folded when the producing layer is a SIREN layer of whole 256-column tiles
   size_t o_sigpart = 0, o_sunpart = 0, o_finpart = 0;
   bool nd_sig = false, nd_sun = false;
+  // the whole SIREN trunk as ONE persistent launch with the activation tile resident in LDS (bsp_trunk.hip): one plane, W = 512, gamma
+  // of 64 columns; training passes leave every layer's planes / sign words for the backward pass (round 5)
+  bool fuse_trunk = false;
   bool nd_fin = false;   // the final layers of the rgb / semantic / beta heads ride in the fused first head layer's epilogue (H = 256: one column tile per head)
   // backward scratch
   size_t o_dza = 0, o_dzb = 0, o_dsa = 0, o_dsb = 0, o_dsig = 0, o_dfin = 0, o_dsun = 0;

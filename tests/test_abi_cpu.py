@@ -70,7 +70,7 @@ def test_host_only_sizes_and_errors():
     assert L.snerf_workspace_bytes(C.byref(ModelSpec(fc_units=96, feat_last=48).desc(16, 8))) > 0
     # the default arithmetic is the same object for a C caller (flags = 0) and for Python's ModelSpec()
     assert L.snerf_workspace_bytes(C.byref(ModelSpec().desc(64, 8))) == L.snerf_workspace_bytes(C.byref(ModelSpec().desc(64, 8, _lib.FLAG_F16X2)))
-    assert L.snerf_version() == 4
+    assert L.snerf_version() == 5
 
 
 def test_plan_builder_over_model_variants_and_null_arguments():

@@ -28,8 +28,8 @@ def _touches(line: str, reg: int) -> bool:
     return False
 
 
-SRCS = ("profile", "bsp_kc", "bsp_gemm", "bsp_aux", "bsp_pass", "aux_kernels", "composite", "loss", "optim", "api")
-NO_SLP = ("bsp_kc", "bsp_gemm")     # csrc/Makefile: CXXFLAGS += -fno-slp-vectorize for these two
+SRCS = ("profile", "bsp_kc", "bsp_trunk", "bsp_gemm", "bsp_aux", "bsp_pass", "aux_kernels", "composite", "loss", "optim", "api")
+NO_SLP = ("bsp_kc", "bsp_trunk", "bsp_gemm")     # csrc/Makefile: CXXFLAGS += -fno-slp-vectorize for these
 
 
 @pytest.fixture(scope="module")
@@ -103,3 +103,23 @@ def test_tile_counter_atomic_result_is_untouched_until_its_wait(device_asm):
                 break
             assert not _touches(ln, dest), f"v{dest} (tile-counter atomic of line {i + 1}) is touched at line {j + 1} before the k-loop's drain: {ln.strip()}"
         assert waited, f"no vmcnt(0) drain behind the atomic of line {i + 1}"
+
+
+def test_trunk_tile_counter_atomic_is_untouched_through_its_k_loop(device_asm):
+    """bsp_trunk.hip draws the next tile the same way, in front of layer 1's k-loop, and reads the result right behind the barrier that
+    ends the loop: in the generated code nothing may name the register between the atomic and that barrier, and the loop's counted
+    waits (vmcnt(4): everything but the youngest sub-step's weight requests has landed) must lie in between."""
+    lines = device_asm["bsp_trunk"]
+    atomics = [i for i, ln in enumerate(lines) if "global_atomic_add" in ln and " sc0" in ln]
+    assert len(atomics) == 2, len(atomics)           # inference and training instantiation
+    for i in atomics:
+        dest = int(re.search(r"global_atomic_add\s+v(\d+),", lines[i]).group(1))
+        counted = 0
+        for j in range(i + 1, len(lines)):
+            ln = lines[j].split(";")[0]
+            if "s_barrier" in ln:
+                break
+            assert not ln.strip().startswith("s_endpgm")
+            counted += bool(re.search(r"s_waitcnt\s+vmcnt\(4\)", ln))
+            assert not _touches(ln, dest), f"v{dest} (tile-counter atomic of line {i + 1}) is touched at line {j + 1} inside the k-loop: {ln.strip()}"
+        assert counted >= 4, counted
