@@ -146,6 +146,9 @@ struct KcArgs {
   const char* H = nullptr; const int* EH = nullptr; int ldh = 0; int h_col0 = 0; const unsigned* Hsign = nullptr;
   float* colsum = nullptr; int ldcs = 0;   // partial column sums of the stored values, one row per 128-row tile (bias gradients)
   int tiles_i = 0, tiles_j = 0;
+  int tj_skip = -1;                  // >= 0: column tile tj_skip is NOT computed (a head block nobody asked for: the beta block of the fused first head
+                                     // layer in a frame that wants rgb / depth / labels only); tiles_j then counts the computed tiles, tiles_jr all of them
+  int tiles_jr = 0;
   int rev = 0;                       // walk the tiles of every XCD group backwards (tiles.h)
   int dbg = 0;                       // diagnostic builds only (bsp_kc.hip: DIAG); ignored by the product kernels
   int* tile_ctr = nullptr;           // 8 zeroed ints (one 64-byte slot per launch): tiles beyond the first are drawn from them; null: fixed shares
@@ -178,12 +181,16 @@ struct DwArgs {
 
 // ---- the SIREN trunk as one persistent launch (bsp_trunk.hip; one plane, W = 512, gamma of 64 columns) -----------------------------
 constexpr int TR_MAXL = 8;
+constexpr int TR_SLOTS = TR_MAXL + 1;   // + the feats layer as entry L of the per-layer arrays
 struct TrunkArgs {
   const char* pe = nullptr; const int* Epe = nullptr;       // gamma(x): one-plane tensor [P][64] + its exponent per 128 points
   int P = 0, W = 0, L = 0; unsigned skip_mask = 0;
   int gamma_free_layer = 0;                                  // filled by launch_trunk: the last layer that reads gamma (>= 2)
-  const char* Wp[TR_MAXL] = {}; const int* EW[TR_MAXL] = {}; unsigned w_bytes[TR_MAXL] = {}; int K[TR_MAXL] = {};   // WF16 packs (one plane), K: 64 | 512 | 576
-  const float* bias[TR_MAXL] = {}; float w0[TR_MAXL] = {};
+  const char* Wp[TR_SLOTS] = {}; const int* EW[TR_SLOTS] = {}; unsigned w_bytes[TR_SLOTS] = {}; int K[TR_SLOTS] = {};   // WF16 packs (one plane), K: 64 | 512 | 576
+  const float* bias[TR_SLOTS] = {}; float w0[TR_SLOTS] = {};
+  // feats = W_f h + b_f (no activation) behind the last SIREN layer, as entry L of the arrays above: planes [P][ldf] at column 0 + one
+  // exponent per (128 points, 128 columns); null: the trunk alone (the last layer's planes leave instead)
+  char* F = nullptr; int* EF = nullptr; int ldf = 0;
   char* H[TR_MAXL] = {}; int* EH[TR_MAXL] = {}; unsigned* Hsign[TR_MAXL] = {};   // outputs [P][W] one plane: the last layer always, every layer when training
   const float* nd_w = nullptr; float* nd_out = nullptr; unsigned long long nd_stride = 0;   // sigma's projection: 8 partial sums per point
   int* tile_ctr = nullptr;                                   // 8 zeroed ints

@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     const kargs_t a = kargs();
     const int l = opaque(lane);
     tile_of_block(vb, tiles_i, tiles_j, ti, tj, a->rev != 0);
+    if (a->tj_skip >= 0 && tj >= a->tj_skip) ++tj;        // (a column tile left out: KcArgs::tj_skip)
     i0 = ti * 128; j0 = tj * 256;
     const int lda = a->lda;
     const int i0a = (DIAG && (a->dbg & 8)) ? 0 : i0;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
     // column tile tj owns rows nd_row0[tj] .. + nd_rows[tj] of nd_w (leading dimension nd_ldw), its 256 columns of them, at nd_woff[tj]
     const float* ndw = p->nd_w;
     float* snd0 = reinterpret_cast<float*>(lds + KC_NDW);
-    for (int tjx = 0; tjx < tiles_j; ++tjx) {
+    for (int tjx = 0; tjx < p->tiles_jr; ++tjx) {
       const int nr = p->nd_rows[tjx], r0 = p->nd_row0[tjx], wo = p->nd_woff[tjx], ldw = p->nd_ldw;
       for (int o = 0; o < nr; ++o) snd0[wo + 256 * o + t] = (256 * tjx + t < p->J) ? ndw[(size_t)(r0 + o) * ldw + 256 * tjx + t] : 0.f;
     }
@@ -772,13 +773,15 @@ int launch_kc(const KcArgs& a0, hipStream_t st) {
   if (rc) return rc;
   if (cs_bias_check(a)) return SNERF_ERR_BAD_DESC;
   a.tiles_i = (a.I + 127) / 128;
-  a.tiles_j = (a.J + 255) / 256;
+  a.tiles_jr = (a.J + 255) / 256;
+  if (a.tj_skip >= a.tiles_jr || (a.tj_skip >= 0 && a.tiles_jr < 2)) { set_error("bsp gemm: tj_skip beyond the column tiles"); return SNERF_ERR_BAD_DESC; }
+  a.tiles_j = a.tiles_jr - (a.tj_skip >= 0 ? 1 : 0);
   if (a.nd_w != nullptr) {   // the projections' LDS layout: column tile tj's rows at nd_woff[tj], 256 floats each
-    if (a.nd_omax == 0) { a.nd_omax = 1; a.nd_ldw = 0; for (int tj = 0; tj < 8; ++tj) { a.nd_rows[tj] = tj < a.tiles_j ? 1 : 0; a.nd_row0[tj] = 0; } }
+    if (a.nd_omax == 0) { a.nd_omax = 1; a.nd_ldw = 0; for (int tj = 0; tj < 8; ++tj) { a.nd_rows[tj] = tj < a.tiles_jr ? 1 : 0; a.nd_row0[tj] = 0; } }
     int off = 0;
-    for (int tj = 0; tj < a.tiles_j && tj < 8; ++tj) { a.nd_woff[tj] = off; off += 256 * a.nd_rows[tj]; }
-    if (a.tiles_j > 8 || off > KC_NDW_FLOATS || (a.nd_omax != 1 && a.nd_omax != 5)) { set_error("bsp gemm: folded projections beyond the LDS table"); return SNERF_ERR_BAD_DESC; }
-    for (int tj = 0; tj < a.tiles_j; ++tj) if (a.nd_rows[tj] > a.nd_omax) { set_error("bsp gemm: nd_rows > nd_omax"); return SNERF_ERR_BAD_DESC; }
+    for (int tj = 0; tj < a.tiles_jr && tj < 8; ++tj) { a.nd_woff[tj] = off; off += 256 * a.nd_rows[tj]; }
+    if (a.tiles_jr > 8 || off > KC_NDW_FLOATS || (a.nd_omax != 1 && a.nd_omax != 5)) { set_error("bsp gemm: folded projections beyond the LDS table"); return SNERF_ERR_BAD_DESC; }
+    for (int tj = 0; tj < a.tiles_jr; ++tj) if (a.nd_rows[tj] > a.nd_omax) { set_error("bsp gemm: nd_rows > nd_omax"); return SNERF_ERR_BAD_DESC; }
   }
 #ifdef KC_DIAG_BUILD
   constexpr bool DIAG = true;

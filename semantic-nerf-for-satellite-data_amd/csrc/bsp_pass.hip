@@ -85,9 +85,17 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
       g.bias[i] = pk + p.b_tr[i];
       g.w0[i] = i == 0 ? 30.f : 1.f;
     }
-    for (int i = p.train ? 0 : p.L - 1; i < p.L; ++i) {   // the layers whose planes leave: all of them for the backward pass, else the last
-      g.H[i] = ws.c(p.o_h[i]); g.EH[i] = ws.i(p.e_h[i]);
-      if (p.train) g.Hsign[i] = ws.u(p.o_c[i]);
+    const bool fused_feats = !p.train;
+    if (fused_feats) {  // feats (rs_semantic.py:338) rides as one more layer: written into the first W columns of the [feats | sun | t | t_s] tensor
+      const int job = p.wj_fs, i = p.L;
+      g.Wp[i] = planes + p.wj_off[job];
+      g.EW[i] = reinterpret_cast<const int*>(planes + p.wp_bytes) + p.wj_e[job];
+      g.w_bytes[i] = (unsigned)bsp::wp16_bytes(p.wj_rows[job], p.wj_K[job], 1);
+      g.K[i] = W; g.bias[i] = pk + p.b_fs; g.w0[i] = 1.f;
+      g.F = ws.c(p.o_fa); g.EF = ws.i(p.e_fa); g.ldf = p.FA;
+    }
+    for (int i = 0; i < p.L && p.train; ++i) {   // training (feats stays a launch of its own): every layer's planes and sign words leave for the backward pass
+      g.H[i] = ws.c(p.o_h[i]); g.EH[i] = ws.i(p.e_h[i]); g.Hsign[i] = ws.u(p.o_c[i]);
     }
     g.nd_w = pk + p.w_fs + (size_t)W * W; g.nd_out = ws.f(p.o_sigpart); g.nd_stride = p.Pp;
     g.tile_ctr = ws.i(p.o_kcq) + 16 * kcq++;
@@ -117,7 +125,7 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
     g.I = P; g.J = NARROW; g.K = W; g.Cf = ws.f(p.o_sigo); g.bias = pk + p.b_fs + W;
     RC(bsp::launch_kc_narrow(g, st));
   }
-  {  // feats (rs_semantic.py:338), written into the first W columns of the [feats | sun | t | t_s] tensor
+  if (!fused || p.train) {  // feats (rs_semantic.py:338), written into the first W columns of the [feats | sun | t | t_s] tensor
     bsp::KcArgs g;
     g.A = hl; g.EA = ehl; g.lda = W; g.Ka = W; weights(g, p, pk, p.wj_fs);
     g.I = P; g.J = W; g.K = W; g.C = ws.c(p.o_fa); g.EC = ws.i(p.e_fa); g.ldc = p.FA; g.bias = pk + p.b_fs;
@@ -134,6 +142,10 @@ int forward_bsp(const Plan& p, const float* pk, const SnerfInputs* in, const Sne
       g.nd_w = pk + p.w_fin; g.nd_ldw = p.KF; g.nd_omax = ND_FIN; g.nd_out = ws.f(p.o_finpart); g.nd_stride = p.Pp;
       auto blk = [&](int b, int col, int n) { if (b >= 0) { g.nd_rows[b] = n; g.nd_row0[b] = col; } };
       blk(p.blk_rgb, Plan::col_rgb, 3); blk(p.blk_sem, Plan::col_sem, p.C); blk(p.blk_beta, Plan::col_beta, 1); blk(p.blk_sbeta, Plan::col_sbeta, 1);
+      // A frame that asks for no beta (full-frame inference: rgb / depth / labels -- eval/extract_pointcloud.py:66-79) does not compute the
+      // beta block: a quarter of this launch.  Only with the finals folded (each block's final rows read its own tile only; the 32-wide
+      // final launch would contract the unwritten columns) and when beta is this pass's only use of the block.
+      if (!p.train && H == 256 && p.blk_beta >= 0 && out->beta == nullptr && !p.rgb_t && p.blk_sbeta < 0) g.tj_skip = p.blk_beta;
     }
     RC(launch_kc(g));
   }

@@ -31,6 +31,7 @@ constexpr int TR_G = TR_A;                      // the encoding tile (one stage)
 constexpr int TR_BIAS = TR_G + 16384;           // 2 x 512 floats: the layer's bias times w0 / 2 pi, by layer parity
 constexpr int TR_NDW = TR_BIAS + 2 * 2048;      // 512 floats: sigma's projection row
 constexpr int TR_NEXT = TR_NDW + 2048;          // the workgroup's next tile
+constexpr int TR_SMAX = TR_NEXT + 32;           // 8 floats: the waves' |max| of the feats layer (two waves share a 128-column exponent block)
 constexpr int TR_EW = TR_NEXT + 64;             // the layers' weight exponents (read once: a global load in an epilogue would be awaited
                                                 //  with vmcnt(0), i.e. behind the next layer's first weight requests)
 constexpr int TR_LDS = TR_EW + 64;
@@ -42,13 +43,17 @@ __device__ __forceinline__ targs_t targs() {
   return q;
 }
 
-template <bool TRAIN>
+// FEATS: the feats layer (no activation, block exponents from the block's own maximum) rides as one more layer behind the last SIREN
+// layer -- inference passes only: together with the sign words of a training pass its two-pass epilogue does not fit the register file
+// (445 spilled registers, scratch traffic inside the hand-counted k-loop).
+template <bool TRAIN, bool FEATS>
 __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
   const targs_t p = targs();
   __shared__ __attribute__((aligned(16))) char lds[TR_LDS];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int L = p->L, ntiles = (p->P + 127) >> 7;
+  const int LT = (FEATS && p->F != nullptr) ? L + 1 : L;   // + the feats layer (entry L of the per-layer arrays): plain epilogue, leaves as planes [P][ldf]
   const unsigned skip_mask = p->skip_mask;
   auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
 
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
   float* const sndw = reinterpret_cast<float*>(lds + TR_NDW);
   sndw[t] = p->nd_w != nullptr ? p->nd_w[t] : 0.f;
   reinterpret_cast<float*>(lds + TR_BIAS)[t] = p->bias[0][t] * (p->w0[0] * INV_2PI);
-  if (t < L) reinterpret_cast<int*>(lds + TR_EW)[t] = *p->EW[t];
+  if (t < LT) reinterpret_cast<int*>(lds + TR_EW)[t] = *p->EW[t];
   int bsel = 0;                                  // which bias buffer the current layer reads
   int* const tile_ctr = p->tile_ctr;
   const int n_grp = (gridDim.x & 7) == 0 ? 8 : 1, grp = (int)blockIdx.x & (n_grp - 1);
@@ -128,11 +133,13 @@ __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
     e_pe = __builtin_amdgcn_readfirstlane(e_pe);
     int next_tile = ntiles;
 
-    for (int l = 0; l < L; ++l) {
+    for (int l = 0; l < LT; ++l) {
       const bool skip = (skip_mask >> l) & 1u;
       const int kofs = (l == 0 || skip) ? 2 : 0;         // sub-steps that read the encoding tile (64 columns)
       const int nks = p->K[l] >> 5;                      // 2 (layer 0), 16, or 18 (skip layer): even
-      const bool last = l == L - 1;
+      const bool last = l == L - 1;                      // the last SIREN layer: sigma's projection
+      const bool isf = FEATS && l == L;                  // the feats layer
+      const bool final = l == LT - 1;                    // the tile ends here
       float* const sbias = reinterpret_cast<float*>(lds + TR_BIAS + bsel * 2048);
       // where sub-step s reads: the encoding tile first (layer 0, skip layer), then the stages of the activation tile
       auto a_base = [&](int s) -> const char* { return s < kofs ? lds + TR_G : lds + ((s - kofs) >> 1) * 16384; };
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
       // the NEXT layer's bias (behind the last layer: layer 0's, whatever tile follows): requested here, consumed right behind the
       // k-loop -- a compiler-visible load is awaited with vmcnt(0) wherever its value is used, and behind the loop nothing but the
       // rejected tail requests is in flight
-      const int ln = last ? 0 : l + 1;
+      const int ln = final ? 0 : l + 1;
       const float bias_next = p->bias[ln][opaque(t)];
       {
         const char* s0 = a_base(0);
@@ -214,21 +221,90 @@ __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
       // the next tile's encoding, once the last layer that reads this tile's has finished (host: gamma_free_layer >= 2)
       const bool more = next_tile < ntiles;
       if (l == e->gamma_free_layer && more) dma_gamma(next_tile);
-      reinterpret_cast<float*>(lds + TR_BIAS + (bsel ^ 1) * 2048)[opaque(t)] = bias_next * (e->w0[ln] * INV_2PI);
+      reinterpret_cast<float*>(lds + TR_BIAS + (bsel ^ 1) * 2048)[opaque(t)] = ln == L ? bias_next : bias_next * (e->w0[ln] * INV_2PI);
       // the next layer's first weights (the next tile's first layer behind the last one)
-      if (!last || more) headW(ln);
+      if (!final || more) headW(ln);
 
       // ---- epilogue: sine, fp16, into stage `wave` of the tile (rows 32 mi + pt, chunk 4 nj + 2 gg + lh) ---------------------------
       const int eWl = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int*>(lds + TR_EW)[l]);
       const int e_in = 13 + eWl + ((l == 0) ? e_pe - 13 : 0);     // acc = true value * 2^e_in
       const float su = pow2f(-e_in) * e->w0[l] * INV_2PI;
       char* const stage = lds + wave * 16384;
-      const bool leave = TRAIN || last;                                // this layer's planes go to device memory
+      const bool leave = TRAIN || isf || (last && LT == L);           // this layer's planes go to device memory
       const int srow = el >> 3, schunk = el & 7;
-      const srd_t srdC = make_srd(leave ? e->H[l] + (size_t)i0 * (size_t)e->W * 2 : nullptr,
-                                  leave ? clamp_bytes(((unsigned long long)(nrows - 1) * e->W + e->W) * 2ull) : 0u);
-      const unsigned voC = (unsigned)srow * (unsigned)e->W * 2u + 128u * (unsigned)wave + 16u * (unsigned)schunk;
-      const unsigned stepC8 = 16u * (unsigned)e->W;                    // eight rows of one plane
+      const int ldo = isf ? e->ldf : e->W;                             // columns of the tensor this layer leaves into
+      const srd_t srdC = make_srd(leave ? (isf ? e->F : e->H[l]) + (size_t)i0 * (size_t)ldo * 2 : nullptr,
+                                  leave ? clamp_bytes(((unsigned long long)(nrows - 1) * ldo + e->W) * 2ull) : 0u);
+      const unsigned voC = (unsigned)srow * (unsigned)ldo * 2u + 128u * (unsigned)wave + 16u * (unsigned)schunk;
+      const unsigned stepC8 = 16u * (unsigned)ldo;                     // eight rows of one plane
+      // the block a wave has just written into its stage is its own store strip: whole 128-byte rows back out, 8 x 128 contiguous
+      // bytes per store (the planes stay alive until the read-back has been consumed: the ds_write data hazard of bsp_kc.hip)
+      auto flush = [&](int mi, const u32x4 (&ph)[4]) {
+#pragma unroll
+        for (int pp = 0; pp < 4; pp += 2) {
+          const int r0 = 32 * mi + 8 * pp + srow, r1 = r0 + 8;
+          const u32x4 d0 = *reinterpret_cast<const u32x4*>(stage + r0 * 128 + 16 * (schunk ^ ((r0 >> 1) & 7)));
+          const u32x4 d1 = *reinterpret_cast<const u32x4*>(stage + r1 * 128 + 16 * (schunk ^ ((r1 >> 1) & 7)));
+          __builtin_amdgcn_raw_buffer_store_b128(d0, srdC, voC, (unsigned)(4 * mi + pp) * stepC8, 2);
+          store_data_guard(d0);
+          __builtin_amdgcn_raw_buffer_store_b128(d1, srdC, voC, (unsigned)(4 * mi + pp + 1) * stepC8, 2);
+          store_data_guard(d1);
+        }
+        asm volatile("" ::"v"(ph[0]), "v"(ph[1]), "v"(ph[2]), "v"(ph[3]));
+      };
+      if (isf) {
+        // ---- feats (rs_semantic.py:338): no activation -- the plain two-pass epilogue of gemm_kc_kernel: values + bias and the block
+        //      |max| (waves 2 c and 2 c + 1 share the exponent block of 128 columns), then fp16 at the block's own exponent
+        const bool e_small = e_in >= -120 && e_in <= 120;
+        if (!e_small) {
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < 2; ++nj) acc[mi][nj] = scale_acc(acc[mi][nj], -e_in);
+        }
+        const float inv_in = e_small ? pow2f(-e_in) : 1.f;
+        float wmax = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int nj = gq >> 1, gg = gq & 1;
+            const float4 b0 = *reinterpret_cast<const float4*>(&sbias[64 * wave + 16 * gq + 8 * lh]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&sbias[64 * wave + 16 * gq + 8 * lh + 4]);
+            float v[8];
+            v[0] = fmaf(acc[mi][nj][8 * gg + 0], inv_in, b0.x); v[1] = fmaf(acc[mi][nj][8 * gg + 1], inv_in, b0.y);
+            v[2] = fmaf(acc[mi][nj][8 * gg + 2], inv_in, b0.z); v[3] = fmaf(acc[mi][nj][8 * gg + 3], inv_in, b0.w);
+            v[4] = fmaf(acc[mi][nj][8 * gg + 4], inv_in, b1.x); v[5] = fmaf(acc[mi][nj][8 * gg + 5], inv_in, b1.y);
+            v[6] = fmaf(acc[mi][nj][8 * gg + 6], inv_in, b1.z); v[7] = fmaf(acc[mi][nj][8 * gg + 7], inv_in, b1.w);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[mi][nj][8 * gg + c] = v[c];
+            const float m8 = absmax3(v[6], v[7], absmax3(v[4], v[5], absmax3(v[2], v[3], absmax3(v[0], v[1], 0.f))));
+            wmax = fmaxf(wmax, (32 * mi + pt) >= nrows ? 0.f : m8);   // (rows beyond P carry the bias: out of the maximum)
+          }
+        wmax = wave_max(wmax);
+        float* const smax = reinterpret_cast<float*>(lds + TR_SMAX);
+        if (el == 0) smax[wave] = wmax;
+        barrier_raw();
+        const float bmax = fmaxf(smax[wave & 6], smax[(wave & 6) + 1]);
+        const int eC = exp_of_maxbits(__float_as_uint(bmax));
+        const float sc = pow2f(eC);
+        if ((wave & 1) == 0 && el == 0) e->EF[(size_t)tile * (size_t)ncb_of(e->ldf) + (wave >> 1)] = eC;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          u32x4 ph[4];
+          const unsigned rsw = (unsigned)(((32 * mi + pt) >> 1) & 7);
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int nj = gq >> 1, gg = gq & 1;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = acc[mi][nj][8 * gg + c];
+            cvt8(v, sc, ph[gq]);
+            *reinterpret_cast<u32x4*>(stage + (32 * mi + pt) * 128 + 16 * ((unsigned)(4 * nj + 2 * gg + lh) ^ rsw)) = ph[gq];
+          }
+          flush(mi, ph);
+        }
+      } else
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
         unsigned sw = 0u;
@@ -255,21 +331,7 @@ __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
           cvt8(v, 8192.f, ph[gq]);
           *reinterpret_cast<u32x4*>(stage + (32 * mi + pt) * 128 + 16 * ((unsigned)(4 * nj + 2 * gg + lh) ^ rsw)) = ph[gq];
         }
-        if (leave) {
-          // the block just written is the wave's own store strip: whole 128-byte rows back out, 8 x 128 contiguous bytes per store
-          // (the planes stay alive until the read-back has been consumed: the ds_write data hazard of bsp_kc.hip)
-#pragma unroll
-          for (int pp = 0; pp < 4; pp += 2) {
-            const int r0 = 32 * mi + 8 * pp + srow, r1 = r0 + 8;
-            const u32x4 d0 = *reinterpret_cast<const u32x4*>(stage + r0 * 128 + 16 * (schunk ^ ((r0 >> 1) & 7)));
-            const u32x4 d1 = *reinterpret_cast<const u32x4*>(stage + r1 * 128 + 16 * (schunk ^ ((r1 >> 1) & 7)));
-            __builtin_amdgcn_raw_buffer_store_b128(d0, srdC, voC, (unsigned)(4 * mi + pp) * stepC8, 2);
-            store_data_guard(d0);
-            __builtin_amdgcn_raw_buffer_store_b128(d1, srdC, voC, (unsigned)(4 * mi + pp + 1) * stepC8, 2);
-            store_data_guard(d1);
-          }
-          asm volatile("" ::"v"(ph[0]), "v"(ph[1]), "v"(ph[2]), "v"(ph[3]));
-        }
+        if (leave) flush(mi, ph);
         if (last && e->nd_out != nullptr) {   // the two lane halves hold the two column halves of every 16-column group of the same point
           const float tot = nd + __shfl_xor(nd, 32, 64);
           if (lh == 0 && 32 * mi + pt < nrows) e->nd_out[(size_t)wave * e->nd_stride + (size_t)(i0 + 32 * mi + pt)] = tot;
@@ -277,11 +339,11 @@ __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
         if (TRAIN && 32 * mi < nrows)
           e->Hsign[l][((size_t)((i0 >> 5) + mi) * (size_t)(e->W >> 6) + (size_t)wave) * 64 + el] = sw;
       }
-      if (leave && (wave & 1) == 0 && el == 0) e->EH[l][(size_t)tile * (size_t)(e->W >> 7) + (wave >> 1)] = 13;
+      if (leave && !isf && (wave & 1) == 0 && el == 0) e->EH[l][(size_t)tile * (size_t)(e->W >> 7) + (wave >> 1)] = 13;
       bsel ^= 1;
       // ---- the new tile is complete --------------------------------------------------------------------------------------------
       barrier_raw();
-      if (last) {
+      if (final) {
         if (!more) return;
         tile = next_tile;
       }
@@ -319,7 +381,7 @@ int launch_trunk(const TrunkArgs& a0, bool train, hipStream_t st) {
     if (a.K[l] != want) return bad_trunk("layer widths: 64 (encoding), 512, 576 (skip)");
     if (!a.Wp[l] || !a.EW[l] || !a.bias[l] || a.w_bytes[l] != (unsigned)wp16_bytes(512, want, 1)) return bad_trunk("weight pack / bias of a layer");
     if (((uintptr_t)a.Wp[l] & 15) || ((uintptr_t)a.bias[l] & 15)) return bad_trunk("alignment");
-    const bool leave = train || l == a.L - 1;
+    const bool leave = train || (l == a.L - 1 && a.F == nullptr);
     if (leave && (!a.H[l] || !a.EH[l] || ((uintptr_t)a.H[l] & 15))) return bad_trunk("output planes of a leaving layer");
     if (train && !a.Hsign[l]) return bad_trunk("sign words (training)");
     if (skip) gfree = l;
@@ -327,6 +389,13 @@ int launch_trunk(const TrunkArgs& a0, bool train, hipStream_t st) {
   a.gamma_free_layer = gfree < 2 ? 2 : gfree;       // >= 2: the next tile's index is known from layer 2 on
   if (a.gamma_free_layer > a.L - 1) a.gamma_free_layer = a.L - 1;
   if (a.nd_out != nullptr && (!a.nd_w || a.nd_stride < (unsigned long long)a.P)) return bad_trunk("sigma projection");
+  if (a.F != nullptr && train) return bad_trunk("the feats layer is fused in inference passes only");
+  if (a.F != nullptr) {     // the feats layer rides as entry L
+    const int l = a.L;
+    if (!a.EF || a.ldf < 512 || (a.ldf & 15) || ((uintptr_t)a.F & 15)) return bad_trunk("feats output");
+    if (a.K[l] != 512 || !a.Wp[l] || !a.EW[l] || !a.bias[l] || a.w_bytes[l] != (unsigned)wp16_bytes(512, 512, 1) || ((uintptr_t)a.Wp[l] & 15) || ((uintptr_t)a.bias[l] & 15))
+      return bad_trunk("feats layer operands");
+  }
   static const int cus = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -336,10 +405,11 @@ int launch_trunk(const TrunkArgs& a0, bool train, hipStream_t st) {
   const int slots = g_trunk_grid_override > 0 ? g_trunk_grid_override : cus;
   const dim3 grid(ntiles < slots ? ntiles : slots), block(512);
   double fl = 0;
-  for (int l = 0; l < a.L; ++l) fl += 2.0 * a.P * 512.0 * a.K[l];
+  for (int l = 0; l < a.L + (a.F != nullptr ? 1 : 0); ++l) fl += 2.0 * a.P * 512.0 * a.K[l];
   const int tok = prof_hook_begin(fl, 4, st);
-  if (train) hipLaunchKernelGGL(trunk_kernel<true>, grid, block, 0, st, a);
-  else hipLaunchKernelGGL(trunk_kernel<false>, grid, block, 0, st, a);
+  if (train) hipLaunchKernelGGL((trunk_kernel<true, false>), grid, block, 0, st, a);
+  else if (a.F != nullptr) hipLaunchKernelGGL((trunk_kernel<false, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((trunk_kernel<false, false>), grid, block, 0, st, a);
   SNERF_LAUNCH_CHECK();
   prof_hook_end(tok, st);
   return SNERF_OK;

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a) {
         const float irr = v + (1.f - v) * k[c];
         if (valid) acc_rgb[c] += (w * al[c]) * irr;
       }
-      const float beta = softplus_f(fin_pre(a, p, Plan::col_beta, 2, 0));
+      const float beta = a.o_beta ? softplus_f(fin_pre(a, p, Plan::col_beta, 2, 0)) : 0.f;   // (not computed when nobody asked: bsp_pass.hip, tj_skip)
       if (valid) {
         acc_depth += w * zj;
         if (a.o_sigmas) a.o_sigmas[p] = sigma;

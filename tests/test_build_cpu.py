@@ -111,7 +111,7 @@ def test_trunk_tile_counter_atomic_is_untouched_through_its_k_loop(device_asm):
     waits (vmcnt(4): everything but the youngest sub-step's weight requests has landed) must lie in between."""
     lines = device_asm["bsp_trunk"]
     atomics = [i for i, ln in enumerate(lines) if "global_atomic_add" in ln and " sc0" in ln]
-    assert len(atomics) == 2, len(atomics)           # inference and training instantiation
+    assert len(atomics) == 3, len(atomics)           # training, inference + feats, inference
     for i in atomics:
         dest = int(re.search(r"global_atomic_add\s+v(\d+),", lines[i]).group(1))
         counted = 0
@@ -123,3 +123,18 @@ def test_trunk_tile_counter_atomic_is_untouched_through_its_k_loop(device_asm):
             counted += bool(re.search(r"s_waitcnt\s+vmcnt\(4\)", ln))
             assert not _touches(ln, dest), f"v{dest} (tile-counter atomic of line {i + 1}) is touched at line {j + 1} inside the k-loop: {ln.strip()}"
         assert counted >= 4, counted
+
+
+def test_hand_counted_kernels_do_not_spill(device_asm):
+    """gemm_kc / gemm_dw / trunk kernels count their vector-memory requests by hand (s_waitcnt vmcnt(N) between asm loads): a spilled
+    register is a scratch load or store the count does not know -- and whether the compiler spills came and went with unrelated edits
+    (bsp_trunk.hip: a compile-time layer count instead of a run-time one spilled 445 registers).  Every instantiation: no spills, no scratch."""
+    n = 0
+    for name in ("bsp_kc", "bsp_trunk", "bsp_gemm"):
+        text = "\n".join(device_asm[name])
+        for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
+            kname, scratch, spills = m.group(1), int(m.group(2)), int(m.group(3))
+            if "gemm_kc_kernel" in kname or "trunk_kernel" in kname or "gemm_dw_kernel" in kname or "gemm_kcn_kernel" in kname:
+                assert scratch == 0 and spills == 0, (kname, scratch, spills)
+                n += 1
+    assert n >= 30, n

@@ -14,6 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from snerf_amd import _lib  # noqa: E402
 
 L = _lib.lib()
+if os.environ.get("SNERF_BENCH_KC_GRID"):      # persistent grid of the K-contiguous launches (default: two workgroups per CU)
+    L.snerf_test_set_kc_grid(int(os.environ["SNERF_BENCH_KC_GRID"]))
 dev = "cuda:0"
 P, W = 262144, 512
 g = torch.Generator().manual_seed(0)
