@@ -37,26 +37,55 @@ import torch  # noqa: E402
 warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
 
 FLOPS_PER_SAMPLE_TRAIN = 31_453_696  # main 3*F_m + sc (F_s + 2*F_s-branch), fc_units=512
+# configs[0], baseline SatNeRF (2,629,632 weights; its sc pass needs trunk + sigma + feats + sun_v = 2,363,904 of them): the same rule
+FLOPS_PER_SAMPLE_TRAIN_SATNERF = 3 * 2 * 2_629_632 + 3 * 2 * 2_363_904 - 1024
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 HBM_ACHIEVABLE_BPS = 6.3e12          # same guide: achievable HBM3E streaming rate (peak 8 TB/s)
 ALGORITHMIC_BYTES_PER_RAY = 3700     # rays + targets in, per-ray results out, parameters amortised
 
 
-def make_cfgs(rays_per_gpu, samples, world, mfma="f16x2"):
+# BASELINE.json `configs`, launchable by name (--config cN).  `rays` is the GLOBAL batch the configuration names and `gpus` the rank
+# count it names: the per-GPU shape (rays / gpus) is what a rank runs, whatever --gpus the launch actually has (weak scaling).
+PRESETS = {
+    "c1": {"name": "configs[0]: JAX_004 baseline SatNeRF, 512 rays x 32 samples (the reference's CPU plumbing case; here on the HIP path)",
+           "rays": 512, "samples": 32, "gpus": 1, "mfma": "f16x2", "model": "satnerf"},
+    "c2": {"name": "configs[1]: JAX_068 semantic pipeline, 4096 rays x 64 samples, 1 GPU, fp32 (the headline)",
+           "rays": 4096, "samples": 64, "gpus": 1, "mfma": "f16x2"},
+    "c3": {"name": "configs[2]: JAX_214 semantic + transient regularisation L_t, 8192 rays x 96 samples, reduced precision, 2 GPUs",
+           "rays": 8192, "samples": 96, "gpus": 2, "mfma": "f16x1", "car_reg": True},
+    "c4": {"name": "configs[3]: JAX_260 semantic, 16384 rays x 128 samples, fp32, 8 GPUs",
+           "rays": 16384, "samples": 128, "gpus": 8, "mfma": "f16x2"},
+    "c5": {"name": "configs[4]: four DFC2019 scenes concatenated, 32768 rays x 128 samples, reduced precision, 8 GPUs + rank-sharded full-frame inference",
+           "rays": 32768, "samples": 128, "gpus": 8, "mfma": "f16x1", "vocab": 96, "frame": True},
+}
+FLOPS_PER_SAMPLE_FWD = 5_640_704     # forward of the semantic model, main pass (the reference's inference cost per sample)
+
+
+def make_cfgs(rays_per_gpu, samples, world, mfma="f16x2", car_reg=False, vocab=50, model="semantic"):
     from snerf_amd.framework.configs import MainConfig
+    if model == "satnerf":       # configs[0]: the baseline pipeline (no positional encoding, no semantic head; baseline/pipelines/satnerf.py)
+        pipeline = {"pipeline": "snerf_amd.baseline.pipelines.satnerf.SatNeRFPipeline", "n_samples": samples, "batch_size": rays_per_gpu * world,
+                    "render_chunk_size": 1 << 22, "learnrate": 5e-4, "fc_units": 512, "fc_layers": 8, "fc_skips": [4], "activation_function": "siren",
+                    "sc_lambda": 0.05, "t_embedding_vocab": vocab, "t_embedding_tau": 4, "first_beta_epoch": 0, "depth_enabled": False,
+                    "mfma_precision": mfma}
+        run = {"max_train_steps": 1 << 30, "synthetic_rays": max(1 << 20, rays_per_gpu * world * 4), "synthetic_images": 19,
+               "synthetic_seed": 0, "shuffle_dataset": True}
+        return MainConfig(run=run, pipeline=pipeline)
     pipeline = {
         "pipeline": "snerf_amd.semantic.pipelines.rs_semantic.RSSemanticPipeline",
         # configs/pipelines/rs_semantic.toml values
         "n_samples": samples, "batch_size": rays_per_gpu * world, "render_chunk_size": 1 << 22,
         "learnrate": 5e-4, "fc_units": 512, "fc_layers": 8, "fc_skips": [4], "activation_function": "siren",
-        "mapping_pos_n_freq": 10, "sc_lambda": 0.05, "t_embedding_vocab": 50, "t_embedding_tau": 4,
+        "mapping_pos_n_freq": 10, "sc_lambda": 0.05, "t_embedding_vocab": vocab, "t_embedding_tau": 4,
         "lambda_s": 0.04, "semantic_activation_function": "sigmoid", "ignore_car_index": True,
         # steady state of training: beta loss active (epoch >= first_beta_epoch), depth rays dropped
         # (after 25 % of the steps, baseline/pipelines/satnerf.py:26-29) -- SURVEY.md 8(d)
         "first_beta_epoch": 0, "depth_enabled": False, "mfma_precision": mfma,
     }
-    run = {"max_train_steps": 1 << 30, "synthetic_rays": max(1 << 20, rays_per_gpu * world * 4), "synthetic_images": 19,
+    if car_reg:      # configs[2]: + the transient regularisation L_t, active from the first epoch on (the bench never leaves epoch 0)
+        pipeline.update(use_car_reg_loss=True, car_reg_loss_start=0)
+    run = {"max_train_steps": 1 << 30, "synthetic_rays": max(1 << 20, rays_per_gpu * world * 4), "synthetic_images": min(19, vocab - 1) if vocab <= 50 else 76,
            "synthetic_seed": 0, "shuffle_dataset": True}
     return MainConfig(run=run, pipeline=pipeline)
 
@@ -144,14 +173,21 @@ def inference_rates(pipe, cfgs, device, samples, n_rays=40960 * 4):
             torch.cuda.empty_cache()
     finally:
         cfgs.pipeline.render_chunk_size = old
-    pi = os.path.join(ROOT, "profiles", "r04", "pmc_inference.json")
-    if os.path.isfile(pi) and samples == 64:
-        try:
-            pj = json.load(open(pi))
-            out["hbm_bytes_per_ray"] = pj["lean"]["hbm_bytes_per_ray"]
-            out["hbm_bytes_source"] = {"file": "profiles/r04/pmc_inference.json", "how": pj.get("how")}
-        except Exception:
-            pass
+    mode = pipe.models["coarse"].spec.mfma
+    for rr in ("r05", "r04"):       # HBM bytes per ray: PMC passes of their own (tools/pmc_inference.sh), newest committed summary of this mode
+        pi = os.path.join(ROOT, "profiles", rr, "pmc_inference.json" if mode == "f16x2" else "pmc_inference_f16x1.json")
+        if os.path.isfile(pi) and samples == 64:
+            try:
+                pj = json.load(open(pi))
+                out["hbm_bytes_per_ray"] = pj["lean"]["hbm_bytes_per_ray"]
+                out["hbm_bytes_source"] = {"file": os.path.relpath(pi, ROOT), "how": pj.get("how")}
+                break
+            except Exception:
+                pass
+    # forward-only work against the matrix peak: the reference's forward FLOPs per sample (all heads) x samples x rays/s, algorithmic
+    # (the three products of the default arithmetic are not counted); the lean path leaves out what the frame does not ask for
+    out["frac"] = out["lean_rays_per_s"] * samples * FLOPS_PER_SAMPLE_FWD / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+    out["mode"] = mode
     out.update(unit="rays/s", rays=n_rays, samples=samples, render_chunk_size=40960,
                lean="rgb + depth + semantic_label, main pass only", batched="all results of render_rays incl. solar-correction pass")
     return out
@@ -163,10 +199,7 @@ def reduced_precision_leg(rays, samples, device, steps=10, warmup=4):
     from snerf_amd.framework.pipelines import load_pipeline, TrainLoop
     ops.release_workspaces()
     torch.cuda.empty_cache()
-    cfgs = make_cfgs(rays, samples, 1, "f16x1")
-    if samples == 96:
-        cfgs.pipeline.use_car_reg_loss = True     # configs[2]: semantic + transient regularisation L_t ...
-        cfgs.pipeline.car_reg_loss_start = 0      # ... active from the first epoch on (the bench never leaves epoch 0)
+    cfgs = make_cfgs(rays, samples, 1, "f16x1", car_reg=samples == 96)   # configs[2]: semantic + transient regularisation L_t
     pipe = load_pipeline(cfgs)
     pipe.log_metrics = False
     loop = TrainLoop(pipe, cfgs, device)
@@ -181,14 +214,19 @@ def reduced_precision_leg(rays, samples, device, steps=10, warmup=4):
     dt = (time.perf_counter() - t0) / steps
     res = {"mode": "f16x1", "dtype": "f16 (one block-scaled fp16 plane; REDUCED)", "rays": rays, "samples": samples, "rays_per_s": rays / dt,
            "ms_per_step": dt * 1e3, "steps": steps, "final_loss": float(out["loss"].detach()),
-           "config": "configs[2] shape (semantic + L_t)" if samples == 96 else "configs[4] per-GPU shape"}
-    if samples == 128:      # configs[4]'s second half: full-frame forward-only rendering (eval/extract_pointcloud.py) in the same mode
+           "config": {96: "configs[2] shape (semantic + L_t)", 128: "configs[4] per-GPU shape"}.get(
+               samples, "the headline shape (configs[1]) in the mode the reference's template default float32_matmul_precision = 'high' maps to under mfma_precision = 'auto'")}
+    if samples != 96:       # full-frame forward-only rendering (eval/extract_pointcloud.py) in the same mode: configs[4]'s second half at S = 128
         del loop, out
         ops.release_workspaces()
         torch.cuda.empty_cache()
         inf = inference_rates(pipe, cfgs, device, samples, n_rays=40960 * 2)
         res["lean_inference_rays_per_s"] = inf["lean_rays_per_s"]
         res["lean_inference_rays"] = inf["rays"]
+        res["lean_inference_frac"] = inf["frac"]
+        if "hbm_bytes_per_ray" in inf:
+            res["lean_inference_hbm_bytes_per_ray"] = inf["hbm_bytes_per_ray"]
+        res["lean_inference_note"] = "trunk + feats as ONE persistent launch with the activation tile resident in LDS (csrc/bsp_trunk.hip)"
         loop = out = None
     del loop, pipe, out
     ops.release_workspaces()
@@ -267,7 +305,8 @@ def rehearsal(args):
             "metric": f"train rays/sec ({args.rays} rays x {args.samples} samples)", "value": args.rays * world * args.steps / dt, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "rehearsal (collectives only, no kernels)", "rehearsal": True,
-            "config": {"workload": "launch / rendezvous / collective protocol only", "rays_per_gpu": args.rays, "samples": args.samples,
+            "config": {"workload": "launch / rendezvous / collective protocol only", "preset": args.config, "mfma": args.mfma,
+                       "rays_per_gpu": args.rays, "samples": args.samples,
                        "global_batch": args.rays * world, "parallelism": f"dp{world}",
                        "distributed": {"backend": dist.get_backend() if world > 1 else None, "world_size": world,
                                        "gradient_bucket_floats": int(bucket.numel())}}}))
@@ -287,15 +326,17 @@ def cpu_model():
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (default: 1, or the rank count the --config names)")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--rays", type=int, default=4096, help="rays per GPU")
-    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--config", default=None, choices=sorted(PRESETS), help="a BASELINE.json configuration by name: c1 ... c5 (per-GPU shape, arithmetic, "
+                    "loss set and rank count of configs[0] ... configs[4]); without it: --rays / --samples / --mfma (default = c2, the headline)")
+    ap.add_argument("--rays", type=int, default=None, help="rays per GPU (default 4096)")
+    ap.add_argument("--samples", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-GEMM HIP-event timing")
     ap.add_argument("--serial-passes", action="store_true", help="run main and sc pass on one stream (as the roofline phase does)")
-    ap.add_argument("--mfma", default="f16x2", choices=["f16x2", "f16x1"],
+    ap.add_argument("--mfma", default=None, choices=["f16x2", "f16x1"],
                     help="matrix arithmetic: f16x2 (default, headline: fp32-class); f16x1 = the REDUCED-precision mode of BASELINE configs[2]/[4] "
                          "(one fp16 plane; reported under its own dtype, never as the fp32 headline)")
     ap.add_argument("--no-reduced", action="store_true", help="skip the reduced-precision legs (4096 x 96 and 4096 x 128 in f16x1)")
@@ -303,6 +344,15 @@ def main():
     ap.add_argument("--no-inference", action="store_true", help="skip the forward-only (full-frame inference) leg")
     ap.add_argument("--rehearsal", action="store_true", help="multi-rank protocol only (collectives, no kernels): CPU rigs")
     args = ap.parse_args()
+    preset = PRESETS.get(args.config or "", None)
+    if preset is not None:
+        if args.rays is not None or args.samples is not None or args.mfma is not None:
+            raise SystemExit("--config fixes the shape and the arithmetic: drop --rays / --samples / --mfma")
+        args.rays, args.samples, args.mfma = preset["rays"] // preset["gpus"], preset["samples"], preset["mfma"]
+        if args.gpus is None:
+            args.gpus = preset["gpus"]
+    args.gpus = args.gpus or 1
+    args.rays, args.samples, args.mfma = args.rays or 4096, args.samples or 64, args.mfma or "f16x2"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)   # no launcher: be the launcher (before anything touches the GPU)
     if args.rehearsal:
@@ -323,7 +373,8 @@ def main():
         from snerf_amd.semantic.components import rendering as _r0
         _r0.OVERLAP_SC_PASS = False
     torch.manual_seed(0)
-    cfgs = make_cfgs(args.rays, args.samples, world, args.mfma)
+    pz = preset or {}
+    cfgs = make_cfgs(args.rays, args.samples, world, args.mfma, car_reg=pz.get("car_reg", False), vocab=pz.get("vocab", 50), model=pz.get("model", "semantic"))
     pipe = load_pipeline(cfgs)
     pipe.log_metrics = False  # the reference logs per-step scalars lazily; no host sync inside the timed region
     loop = TrainLoop(pipe, cfgs, device)
@@ -421,12 +472,43 @@ def main():
     dt = float(tmax.item())
     loss = float(out["loss"].detach())
 
+    if pz.get("frame"):
+        # configs[4]'s second half: full-frame inference a la eval/extract_pointcloud.py with the frame's rays sharded over the ranks
+        # (eval/utils/util.py: sharded_lean_inference -- every rank renders ceil(n / world) rays, one all_gather per per-ray result)
+        from snerf_amd.eval.utils.util import sharded_lean_inference
+        from snerf_amd.framework.datasets import GpuRayBank
+        from snerf_amd import ops as _ops
+        del out
+        _ops.release_workspaces()
+        torch.cuda.empty_cache()
+        n_frame = 640 * 640
+        fb = GpuRayBank.synthetic(n_frame, 19, 5, 321, device=device)
+        old_chunk = cfgs.pipeline.render_chunk_size
+        cfgs.pipeline.render_chunk_size = 40960
+        try:
+            sharded_lean_inference(cfgs, pipe.renderer, pipe.models, fb.t["rays"][:40960 * world], fb.t["extras"][:40960 * world])
+            barrier()
+            tf0 = time.perf_counter()
+            fr = sharded_lean_inference(cfgs, pipe.renderer, pipe.models, fb.t["rays"], fb.t["extras"])
+            barrier()
+            tf = time.perf_counter() - tf0
+        finally:
+            cfgs.pipeline.render_chunk_size = old_chunk
+        tfm = torch.tensor([tf], dtype=torch.float64, device="cpu" if gloo else device)
+        if world > 1:
+            torch.distributed.all_reduce(tfm, op=torch.distributed.ReduceOp.MAX)
+        frame_leg = {"rays": n_frame, "samples": args.samples, "world_size": world, "rays_per_s": n_frame / float(tfm.item()), "ms": float(tfm.item()) * 1e3,
+                     "results": "rgb + depth + semantic_label of the WHOLE frame on every rank", "render_chunk_size": 40960,
+                     "frame_rows_on_rank0": int(fr["rgb_coarse"].shape[0])}
+        del fr, fb
+    else:
+        frame_leg = None
     if rank != 0:
         return
     mode = pipe.models["coarse"].spec.mfma
     rays_total = args.rays * world * args.steps
     value = rays_total / dt
-    flops_step_gpu = FLOPS_PER_SAMPLE_TRAIN * args.rays * args.samples
+    flops_step_gpu = (FLOPS_PER_SAMPLE_TRAIN_SATNERF if pz.get("model") == "satnerf" else FLOPS_PER_SAMPLE_TRAIN) * args.rays * args.samples
     reduced = {"f16x1": "f16 (REDUCED: one block-scaled fp16 plane)"}
     line = {
         "metric": f"train rays/sec ({args.rays} rays x {args.samples} samples)", "value": value, "unit": "rays/s", "n_gpus": world,
@@ -442,10 +524,14 @@ def main():
             "f16x1": "REDUCED (the reference's precision = 16 runs): the same block-scaled tensors with ONE fp16 plane (11 significant bits, 2 bytes "
                      "per element), one product per contraction step on v_mfma_f32_32x32x16_f16, fp32 accumulate"}[mode],
         "data": "synthetic",
-        "config": {"workload": "JAX_068 semantic pipeline (configs[1]): RSSemanticNeRF fc_units=512 x 8 layers, C=5, "
-                               f"{args.rays} rays x {args.samples} samples per GPU, fp32, main + solar-correction pass, "
-                               "SatNerfLoss + sc + SemanticLoss(ignore car), Adam lr 5e-4; synthetic rays (SURVEY 8d), "
-                               "random-init SIREN weights",
+        "config": {"workload": ((preset["name"] + f" -- per GPU {args.rays} rays x {args.samples} samples, {args.mfma}; ") if preset else
+                                "JAX_068 semantic pipeline (configs[1]): ") +
+                               ("SatNeRF fc_units=512 x 8 layers (no encoding, no semantic head), main + solar-correction pass, SatNerfLoss + sc, "
+                                if pz.get("model") == "satnerf" else
+                                "RSSemanticNeRF fc_units=512 x 8 layers, C=5, " + ("" if preset else f"{args.rays} rays x {args.samples} samples per GPU, fp32, ") +
+                                "main + solar-correction pass, SatNerfLoss + sc + SemanticLoss(ignore car)" + (" + L_t" if pz.get("car_reg") else "") + ", ") +
+                               "Adam lr 5e-4; synthetic rays (SURVEY 8d), random-init SIREN weights",
+                   "preset": args.config,
                    "rays_per_gpu": args.rays, "samples": args.samples, "global_batch": args.rays * world,
                    "parallelism": f"dp{world}", "final_loss": loss,
                    "streams": "main pass and solar-correction pass on two HIP streams" if not args.serial_passes else "single stream"},
@@ -471,7 +557,7 @@ def main():
         # read from the newest committed PMC summary of this workload, with its provenance next to it
         traffic, traffic_source = None, None
         step_hbm, step_src = None, None
-        for rr in ("r04", "r03", "r02"):
+        for rr in ("r05", "r04", "r03", "r02"):
             tf = os.path.join(ROOT, "profiles", rr, "pmc_hbm_traffic.json")
             if os.path.isfile(tf) and mode == "f16x2" and args.rays == 4096 and args.samples == 64:
                 try:
@@ -520,13 +606,16 @@ def main():
         line["roofline"] = {"bound": "mfma", "achieved": step_tflops, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": step_tflops / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
                             "kernel": "whole step (algorithmic FLOPs / wall time); per-kernel timing disabled"}
+    if frame_leg is not None:
+        line["inference_sharded"] = frame_leg
     if world == 1 and not args.no_inference:
         line["inference"] = inference_rates(pipe, cfgs, device, args.samples)
-    if world == 1 and not args.no_reduced and mode == "f16x2":
+    if world == 1 and not args.no_reduced and mode == "f16x2" and preset is None:
         # BASELINE configs[2] / [4] name reduced precision (the reference's `precision = 16`): the same step in the one-plane mode at
-        # their per-GPU shapes.  Reported here, never in `value`.
+        # their per-GPU shapes, and at the headline shape (what the reference's template default float32_matmul_precision = "high" maps to
+        # under mfma_precision = "auto").  Reported here, never in `value`.
         del loop, pipe
-        line["reduced_precision"] = [reduced_precision_leg(4096, S, device) for S in (96, 128)]
+        line["reduced_precision"] = [reduced_precision_leg(4096, S, device) for S in (64, 96, 128)]
         loop = pipe = None
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args.samples)

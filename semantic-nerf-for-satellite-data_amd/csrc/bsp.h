@@ -194,6 +194,7 @@ struct TrunkArgs {
   char* H[TR_MAXL] = {}; int* EH[TR_MAXL] = {}; unsigned* Hsign[TR_MAXL] = {};   // outputs [P][W] one plane: the last layer always, every layer when training
   const float* nd_w = nullptr; float* nd_out = nullptr; unsigned long long nd_stride = 0;   // sigma's projection: 8 partial sums per point
   int* tile_ctr = nullptr;                                   // 8 zeroed ints
+  int dbg = 0;                                               // diagnostic builds only (bsp_trunk.hip: TRUNK_DIAG_BUILD); ignored by the product kernels
 };
 int launch_trunk(const TrunkArgs& a, bool train, hipStream_t st);
 void trunk_set_grid_override(int n);                       // test hook: persistent grid of n workgroups (0: one per CU)

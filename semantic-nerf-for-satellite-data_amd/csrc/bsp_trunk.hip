@@ -46,9 +46,19 @@ __device__ __forceinline__ targs_t targs() {
 // FEATS: the feats layer (no activation, block exponents from the block's own maximum) rides as one more layer behind the last SIREN
 // layer -- inference passes only: together with the sign words of a training pass its two-pass epilogue does not fit the register file
 // (445 spilled registers, scratch traffic inside the hand-counted k-loop).
+// (TRUNK_DIAG_BUILD: tools/ablate/build_diag.sh only -- TrunkArgs::dbg 1: the weight descriptor has size zero, 2: the sine epilogue's
+//  arithmetic and LDS writes are skipped, 4: no fragment reads inside the k-loop.  Timing only; the product build carries none of it.)
+#ifdef TRUNK_DIAG_BUILD
+#define TRUNK_DBG(bit) (dbg & (bit))
+#else
+#define TRUNK_DBG(bit) false
+#endif
 template <bool TRAIN, bool FEATS>
 __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
   const targs_t p = targs();
+#ifdef TRUNK_DIAG_BUILD
+  const int dbg = p->dbg;
+#endif
   __shared__ __attribute__((aligned(16))) char lds[TR_LDS];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -105,7 +115,7 @@ __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
   BFrag bq0, bq1, bq2;
   auto headW = [&](int l) {     // sub-steps 0 and 1 of layer l
     const targs_t a = targs();
-    srdW = make_srd_words(a->Wp[l], a->w_bytes[l]);
+    srdW = make_srd_words(a->Wp[l], TRUNK_DBG(1) ? 0u : a->w_bytes[l]);
     nks16 = a->K[l] >> 4;
     loadB2(0, bq0, 0); loadB2(0, bq0, 1); loadB2(1, bq1, 0); loadB2(1, bq1, 1);
   };
@@ -173,11 +183,11 @@ __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
           acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh0, fa.h[mi], acc[mi][0], 0, 0, 0);
           acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh1, fa.h[mi], acc[mi][1], 0, 0, 0);
           if (mi < 2) loadB2(s + 2, bn, mi);
-          const f16x8 nh = ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);   // fa.h[mi] has issued its last MFMA
+          const f16x8 nh = TRUNK_DBG(4) ? fa.h[mi] : ldsfrag(sn + 4096 * mi + fo[u ^ 1][0]);   // fa.h[mi] has issued its last MFMA
           acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl0, fa.l[mi], acc[mi][0], 0, 0, 0);
           acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl1, fa.l[mi], acc[mi][1], 0, 0, 0);
           fa.h[mi] = nh;
-          fa.l[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
+          if (!TRUNK_DBG(4)) fa.l[mi] = ldsfrag(sn + 4096 * mi + fo[u ^ 1][1]);
           __builtin_amdgcn_sched_barrier(0);
         }
       };
@@ -304,6 +314,13 @@ __global__ __launch_bounds__(512, 1) void trunk_kernel(const TrunkArgs) {
           }
           flush(mi, ph);
         }
+      } else if (TRUNK_DBG(2)) {
+        float keep = 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int nj = 0; nj < 2; ++nj) keep += acc[mi][nj][0];
+        if (keep == 12345.678f) sndw[0] = keep;
       } else
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) {
@@ -401,6 +418,9 @@ int launch_trunk(const TrunkArgs& a0, bool train, hipStream_t st) {
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     return n;
   }();
+#ifdef TRUNK_DIAG_BUILD
+  { const char* ev = getenv("SNERF_TRUNK_DBG"); a.dbg = ev ? atoi(ev) : 0; }
+#endif
   const int ntiles = (a.P + 127) / 128;
   const int slots = g_trunk_grid_override > 0 ? g_trunk_grid_override : cus;
   const dim3 grid(ntiles < slots ? ntiles : slots), block(512);

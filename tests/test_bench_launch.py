@@ -30,6 +30,30 @@ def test_bench_spawns_its_ranks_rehearsal_gloo_cpu():
     assert d["config"]["global_batch"] == 128 and d["steps"] == 2 and d["scaling"] == "weak"
 
 
+def test_bench_preset_c3_two_rank_rehearsal():
+    """BASELINE.json configs[2] by name: `bench.py --config c3` brings its own rank count (2), per-GPU shape (8192 / 2 rays x 96 samples)
+    and arithmetic (the reduced-precision mode) -- launched as a plain command, collectives rehearsed on the CPU (gloo)."""
+    d = _run(["--config", "c3", "--rehearsal", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["config"]["distributed"]["world_size"] == 2 and d["rehearsal"] is True
+    c = d["config"]
+    assert c["preset"] == "c3" and c["rays_per_gpu"] == 4096 and c["samples"] == 96 and c["global_batch"] == 8192 and c["mfma"] == "f16x1"
+    # the other presets resolve without a launch: shape / ranks / arithmetic as BASELINE.json names them
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    want = {"c1": (512, 32, 1, "f16x2"), "c2": (4096, 64, 1, "f16x2"), "c3": (8192, 96, 2, "f16x1"), "c4": (16384, 128, 8, "f16x2"), "c5": (32768, 128, 8, "f16x1")}
+    for k, (rays, S, gpus, mfma) in want.items():
+        pz = b.PRESETS[k]
+        assert (pz["rays"], pz["samples"], pz["gpus"], pz["mfma"]) == (rays, S, gpus, mfma), k
+    assert b.PRESETS["c3"]["car_reg"] and b.PRESETS["c5"]["frame"] and b.PRESETS["c1"]["model"] == "satnerf"
+    # a preset's pipeline configuration builds (no GPU needed): L_t on for c3, the raised vocabulary for c5, the baseline pipeline for c1
+    c3 = b.make_cfgs(4096, 96, 2, "f16x1", car_reg=True)
+    assert c3.pipeline.use_car_reg_loss and c3.pipeline.car_reg_loss_start == 0 and c3.pipeline.batch_size == 8192
+    assert b.make_cfgs(4096, 128, 8, "f16x1", vocab=96).pipeline.t_embedding_vocab == 96
+    assert b.make_cfgs(512, 32, 1, model="satnerf").pipeline.pipeline.endswith("SatNeRFPipeline")
+
+
 def test_bench_rank_failure_is_reported():
     env = dict(os.environ, SNERF_BENCH_FAIL_RANK="1")   # rank 1 dies before the rendezvous: the parent must end rank 0 and fail
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
@@ -37,6 +61,20 @@ def test_bench_rank_failure_is_reported():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearsal", "--steps", "1", "--warmup", "0"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
+
+
+@pytest.mark.gpu
+def test_bench_presets_run_on_one_gpu():
+    """every preset's step runs (one rank on this GPU, two steps): c1 the baseline SatNeRF pipeline, c3 the one-plane mode with L_t, c5
+    with the rank-sharded full-frame leg"""
+    common = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-eager-gpu-baseline", "--no-inference", "--no-profile", "--no-reduced"]
+    d = _run(["--config", "c1"] + common)
+    assert d["config"]["preset"] == "c1" and d["config"]["rays_per_gpu"] == 512 and d["config"]["samples"] == 32 and d["value"] > 0
+    d = _run(["--config", "c3"] + common)
+    assert d["config"]["rays_per_gpu"] == 4096 and d["config"]["samples"] == 96 and d["dtype"].startswith("f16 (REDUCED") and "L_t" in d["config"]["workload"]
+    d = _run(["--config", "c5"] + common)
+    assert d["config"]["samples"] == 128 and d["inference_sharded"]["rays"] == 640 * 640 and d["inference_sharded"]["rays_per_s"] > 0
+    assert d["inference_sharded"]["frame_rows_on_rank0"] == 640 * 640
 
 
 @pytest.mark.gpu
