@@ -161,7 +161,8 @@ def inference_rates(pipe, cfgs, device, samples, n_rays=40960 * 4):
     cfgs.pipeline.render_chunk_size = 40960
     out = {}
     try:
-        for name, fn in (("lean", lambda: lean_inference(cfgs, pipe.renderer, pipe.models, rays, extras)),
+        keys = ("rgb_coarse", "depth_coarse", "semantic_label_coarse") if pipe.models["coarse"].spec.n_classes > 0 else ("rgb_coarse", "depth_coarse")
+        for name, fn in (("lean", lambda: lean_inference(cfgs, pipe.renderer, pipe.models, rays, extras, keys=keys)),
                          ("batched", lambda: batched_inference(cfgs, pipe.renderer, pipe.models, rays, extras))):
             fn()
             torch.cuda.synchronize()

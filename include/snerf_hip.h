@@ -266,7 +266,7 @@ int snerf_adam_step(float* params, const float* grads, float* exp_avg, float* ex
  * stream it is launched on; _end synchronises those events and returns, per kernel variant, the summed
  * device time, the algorithmic FLOPs (2*I*J*K of each launch) and the launch count.
  * variant 0: K-contiguous GEMMs (forward X.W^T and dX = dZ.(W^T)^T): gemm_kc_kernel of bsp_kc.hip (128x256 tile),
- *         1: unused,
+ *         1: the SIREN trunk as one persistent launch (trunk_kernel of bsp_trunk.hip; one-plane mode),
  *         2: dW = dZ^T.X (both operands read along the points, split over the points): gemm_dw_kernel (256x256 tile),
  *         3: the 32-wide head variants (gemm_kcn_kernel, gemm_dw_kernel<32>). */
 #define SNERF_PROFILE_VARIANTS 4

@@ -86,7 +86,7 @@ class SnerfProfile(C.Structure):
     _fields_ = [("ms", C.c_double * 4), ("flops", C.c_double * 4), ("launches", C.c_int64 * 4)]
 
 
-PROFILE_VARIANTS = ("K-contiguous dense layers (forward X.W^T and dX = dZ.W): gemm_kc_kernel, 128 x 256 tile", "mixed layouts (unused)",
+PROFILE_VARIANTS = ("K-contiguous dense layers (forward X.W^T and dX = dZ.W): gemm_kc_kernel, 128 x 256 tile", "SIREN trunk as one persistent launch (one-plane mode): trunk_kernel, activation tile resident in LDS",
                     "weight gradients (dW = dZ^T.X, split-K slabs): gemm_dw_kernel, 256 x 256 tile", "32-wide head variants (forward + dW)")
 
 _lib = None

@@ -44,7 +44,8 @@ constexpr int KC_LDS_ND = KC_NDW + 4 * KC_NDW_FLOATS;
 // DIAG (tools/ablate/build_diag.sh only; the product instantiates DIAG = false): KcArgs::dbg removes operand traffic through
 // zero-size descriptors -- 1: A, 2: W (host side), 4: stores, 8: every tile reads the first 128 rows of A (always L2-resident);
 // 16: the epilogue's arithmetic, strips and stores are skipped (tile bookkeeping and next-tile requests stay), 32: no workgroup barrier
-// inside the k-loop, 64: no fragment reads inside the k-loop.  Timing-only: the results are wrong.
+// inside the k-loop, 64: no fragment reads inside the k-loop, 128: the stored activation of a derivative epilogue (zero-size descriptor).
+// Timing-only: the results are wrong.
 // PL = planes per operand / result tensor (bsp.h).  PL = 1: a 16-column group is 32 bytes, so the SAME bytes carry twice the
 // contraction depth -- a "sub-step" below is 64 bytes of every A row = 16 k of two planes (3 products) or 32 k of one plane
 // (1 product per 16 k): same LDS traffic, same request counts, 16 instead of 24 MFMAs per sub-step; a stage (128 bytes per row)
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KcArgs) {
       // c ^ ((q >> 2) & 3) (the 16 points of a ds_read_b128 group then cover the sixteen 16-byte slots of a 256-byte bank row).
       const size_t offH = uniform_sz(AUX != AUX_NONE ? ((size_t)c_i0 * e->ldh + e->h_col0) * EB : 0);
       const srd_words srdH = make_srd_words(AUX != AUX_NONE ? e->H + offH : nullptr,
-                                            AUX != AUX_NONE ? clamp_bytes(((unsigned long long)(nrows - 1) * e->ldh + e->J) * (unsigned long long)EB) : 0u);
+                                            AUX != AUX_NONE && !(DIAG && (dbg & 128)) ? clamp_bytes(((unsigned long long)(nrows - 1) * e->ldh + e->J) * (unsigned long long)EB) : 0u);
       constexpr int HPC = PL == 2 ? 4 : 2;                        // 1 KiB pieces per half-block
       const unsigned hbuf[2] = {(unsigned)__builtin_amdgcn_readfirstlane(lds_addr(lds + 2 * KC_A + wave * 4096)),
                                 (unsigned)__builtin_amdgcn_readfirstlane(lds_addr(lds + KC_XREG + wave * 4096))};

@@ -426,7 +426,7 @@ int launch_trunk(const TrunkArgs& a0, bool train, hipStream_t st) {
   const dim3 grid(ntiles < slots ? ntiles : slots), block(512);
   double fl = 0;
   for (int l = 0; l < a.L + (a.F != nullptr ? 1 : 0); ++l) fl += 2.0 * a.P * 512.0 * a.K[l];
-  const int tok = prof_hook_begin(fl, 4, st);
+  const int tok = prof_hook_begin(fl, 1, st);      // variant 1 of SnerfProfile: the fused trunk
   if (train) hipLaunchKernelGGL((trunk_kernel<true, false>), grid, block, 0, st, a);
   else if (a.F != nullptr) hipLaunchKernelGGL((trunk_kernel<false, true>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((trunk_kernel<false, false>), grid, block, 0, st, a);

@@ -24,7 +24,7 @@ static hipEvent_t prof_event() {
 
 // bracket of one launch: token >= 0 while profiling is on
 int prof_hook_begin(double flops, int variant, hipStream_t st) {
-  if (!g_prof_on) return -1;
+  if (!g_prof_on || variant < 0 || variant >= SNERF_PROFILE_VARIANTS) return -1;
   ProfRec rec{prof_event(), prof_event(), flops, variant};
   if (!rec.a || !rec.b) return -1;
   (void)hipEventRecord(rec.a, st);
