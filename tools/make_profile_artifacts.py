@@ -19,7 +19,7 @@ tot = sum(int(r["TotalDurationNs"]) for r in rows)
 calls = sum(int(r["Calls"]) for r in rows)
 out = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %d --warmup %d --serial-passes --no-cpu-baseline --no-eager-gpu-baseline --no-inference --no-profile --no-reduced" % (u["steps"], u["warmup"]),
        "",
-       "Round 4, 1x MI355X, %s, default arithmetic (block-scaled fp16 planes, three MFMA products)." % u["metric"],
+       "Round 5, 1x MI355X, %s, default arithmetic (block-scaled fp16 planes, three MFMA products)." % u["metric"],
        "%d steps in the trace; `--serial-passes` keeps the main and solar-correction passes on one stream so per-kernel durations" % steps,
        "are not stretched by overlap.  bench.py under the profiler: %.0f rays/s, %.2f ms/step.  Full table: bench_n1_kernel_stats.csv." % (u["value"], u["ms_per_step"]),
        "", "| kernel | calls / step | total ms | avg us | % of device time |", "|---|---|---|---|---|"]
