@@ -168,3 +168,45 @@ def test_fp64_oracle_close_to_fp32():
     b = O.batch_to_torch({k[3:]: z[k] for k in z.files if k.startswith("in_")}, dtype=torch.float64)
     res = O.render_rays(p64, emb, cfg, b["rays"], b["extras"], b["u"])
     assert max_abs(res["rgb_coarse"], z["out_rgb_coarse"]) < 1e-4
+
+
+def test_oracle_trains_like_the_reference_on_the_synthetic_scene():
+    """The first 100 steps of tools/gen_golden.py's convergence_case with the ORACLE in the reference's place: render, gated losses
+    (SNerf loss in epochs 0-1, SatNerf loss from step 80 on), Adam + StepLR(0.9) per epoch on contiguous batches of the learnable
+    scene -- PSNR / accuracy / mIoU / depth error on the held-out rays at steps 0, 50, 100 against the reference's curves."""
+    z, meta, cfg = load_fixture("converge_small")
+    B, every, seed = meta["batch"], meta["eval_every"], meta["seed"]
+    train, test = O.synthetic_scene(meta["n_bank"], meta["n_test"], seed=meta["scene_seed"], n_classes=cfg.n_classes)
+    spe = meta["n_bank"] // B
+    p = O.to_torch(O.init_params_numpy(cfg, seed), requires_grad=True)
+    emb = torch.from_numpy(O.init_embedding_numpy(cfg, seed)).requires_grad_(True)
+    opt = torch.optim.Adam(list(p.values()) + [emb], lr=5e-4, weight_decay=0)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.9)
+    tt = O.batch_to_torch({k: test[k] for k in ("rays", "extras")})
+    u_test = torch.from_numpy(O.scene_jitter(seed, -1, meta["n_test"], cfg.n_samples))
+    got = {k: [] for k in ("psnr", "acc", "miou", "depth_mae")}
+    steps = 2 * every
+    for it in range(steps + 1):
+        if it % every == 0:
+            with torch.no_grad():
+                r = O.render_rays(p, emb, cfg, tt["rays"], tt["extras"], u_test)
+            m = O.scene_metrics(r["rgb_coarse"].numpy(), r["depth_coarse"].numpy(), r["semantic_logits_coarse"].numpy(), test, cfg.car_index)
+            for k, v in m.items():
+                got[k].append(v)
+        if it == steps:
+            break
+        epoch, k = divmod(it, spe)
+        idx = np.arange(k * B, (k + 1) * B) % meta["n_bank"]
+        b = O.batch_to_torch({"rays": train["rays"][idx], "extras": train["extras"][idx], "rgbs": train["rgbs"][idx],
+                              "semantic": train["semantic"][idx], "mask": train["mask"][idx],
+                              "u": O.scene_jitter(seed, it, B, cfg.n_samples)})
+        opt.zero_grad()
+        res = O.render_rays(p, emb, cfg, b["rays"], b["extras"], b["u"])
+        O.total_loss(O.training_losses(res, b, cfg, epoch)).backward()
+        opt.step()
+        if (it + 1) % spe == 0:
+            sched.step()
+    for k, bar in (("psnr", 5e-3), ("acc", 5e-3), ("miou", 5e-3), ("depth_mae", 1e-4)):
+        ref = z["run0_" + k][: len(got[k])]
+        assert np.abs(np.array(got[k]) - ref).max() <= bar, (k, got[k], ref.tolist())
+    assert got["psnr"][-1] > got["psnr"][0] + 8.0

@@ -273,6 +273,73 @@ def trajectory_case(name, cfg: O.OracleCfg, n_rays, seed, steps, final_params=("
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, loss {traj[0]:.6f} -> {traj[-1]:.6f} over {steps} steps")
 
 
+def convergence_case(name, cfg: O.OracleCfg, seed, n_bank, n_test, batch, steps, eval_every, scene_seed=3, perturb_rel=(0.0, 1e-6, 1e-3)):
+    """The BASELINE metric's quality half (PSNR / mIoU / altitude error) where no real scene exists: the reference -- its renderer,
+    its loss modules under the epoch gates of semantic/components/training_step.py:22-92, torch.optim.Adam(lr 5e-4) with
+    StepLR(1, 0.9) per epoch (base_ray_pipeline.py:246-269, framework/util/train_util.py:45-60) -- TRAINED for `steps` steps on the
+    learnable synthetic scene of oracle.synthetic_scene (contiguous batches of the bank, no shuffle, the jitter of step i drawn by
+    oracle.scene_jitter), evaluated on held-out rays every `eval_every` steps.  Run once per entry of `perturb_rel`: from the seeded
+    initial weights, and from those weights times (1 + eps N(0, 1)) -- the spread between the runs is what noise of that size in the weights
+    alone does to these curves (1e-6: fp32 rounding; 1e-3: the 11-bit operands of the reduced-precision mode), i.e. the yardstick for a
+    build that follows the reference within its arithmetic.  Stored: the curves
+    only; scene, weights and jitter regenerate from the seeds."""
+    train, test = O.synthetic_scene(n_bank, n_test, seed=scene_seed, n_classes=cfg.n_classes)
+    spe = max(1, n_bank // batch)
+    fix = {}
+    u_test = torch.from_numpy(O.scene_jitter(seed, -1, n_test, cfg.n_samples))
+    tt = {k: torch.from_numpy(v) for k, v in test.items()}
+    for run, eps in enumerate(perturb_rel):
+        torch.manual_seed(0)
+        cfgs, models, renderer, params = build_reference(cfg, seed)
+        if eps:
+            rng = np.random.default_rng(seed + 99)
+            with torch.no_grad():
+                for p in models["coarse"].parameters():
+                    p.mul_(torch.from_numpy(1.0 + eps * rng.standard_normal(tuple(p.shape))).float())
+        plist = [p for m in models.values() for p in m.parameters()]
+        opt = torch.optim.Adam(plist, lr=5e-4, weight_decay=0)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.9)
+        curves = {k: [] for k in ("step", "loss", "psnr", "acc", "miou", "depth_mae")}
+
+        def evaluate(step, loss):
+            with torch.no_grad():
+                r = render_with_u(renderer, models, tt["rays"], tt["extras"], u_test)
+            m = O.scene_metrics(r["rgb_coarse"].numpy(), r["depth_coarse"].numpy(), r["semantic_logits_coarse"].numpy(), test, cfg.car_index)
+            curves["step"].append(step); curves["loss"].append(loss)
+            for k, v in m.items():
+                curves[k].append(v)
+
+        last = float("nan")
+        for it in range(steps):
+            if it % eval_every == 0:
+                evaluate(it, last)
+            epoch, k = divmod(it, spe)
+            idx = (np.arange(k * batch, (k + 1) * batch)) % n_bank
+            bt = {"rays": torch.from_numpy(train["rays"][idx]), "extras": torch.from_numpy(train["extras"][idx]),
+                  "rgbs": torch.from_numpy(train["rgbs"][idx]), "semantic": torch.from_numpy(train["semantic"][idx]),
+                  "mask": torch.from_numpy(train["mask"][idx])}
+            u = torch.from_numpy(O.scene_jitter(seed, it, batch, cfg.n_samples))
+            opt.zero_grad()
+            r = render_with_u(renderer, models, bt["rays"], bt["extras"], u)
+            l = sum(losses_for_epoch(cfg, r, bt, epoch).values())
+            l.backward()
+            opt.step()
+            last = l.item()
+            if (it + 1) % spe == 0:
+                sched.step()
+        evaluate(steps, last)
+        for k, v in curves.items():
+            fix[f"run{run}_{k}"] = np.array(v, dtype=np.float64)
+        print(f"{name} run {run} (eps {eps}): " + ", ".join(f"{k} {curves[k][0]:.3f} -> {curves[k][-1]:.3f}" for k in ("psnr", "acc", "miou", "depth_mae")))
+    meta = dict(name=name, seed=seed, scene_seed=scene_seed, n_bank=n_bank, n_test=n_test, batch=batch, steps=steps, eval_every=eval_every,
+                perturb_rel=list(perturb_rel), cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(cfg).items()},
+                torch=torch.__version__, reference="wagnva/semantic-nerf-for-satellite-data@2025-03-21")
+    fix["meta_json"] = np.array(json.dumps(meta))
+    path = os.path.join(OUT, f"{name}.npz")
+    np.savez_compressed(path, **fix)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
 FULL_GRADS_SEM = ("fc_net.0.weight", "fc_net.8.weight", "sun_v_net.0.weight", "semantic_prediction.2.weight", "model_t.weight")
 
 
@@ -281,6 +348,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--trajectories":   # only the round-5 additions (the other fixtures regenerate array-identically)
         # I: long optimiser trajectories of the whole composed step -- 25 steps at W = 32 with L_t on, 10 steps at the full width
         make_trajectories()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "--convergence":    # J: the reference trained on the learnable synthetic scene
+        make_convergence()
         return
     small = dict(fc_units=32, n_samples=16, render_chunk_size=200)  # chunk < P: exercises the chunk loop
     # A: default semantic config at reduced width, beta loss active
@@ -311,6 +381,12 @@ def main():
     inference_case("inference_sem_small", O.OracleCfg(**small), 24, seed=10)
     inference_case("inference_satnerf_small", O.OracleCfg(model="satnerf", fc_units=32, n_samples=8), 24, seed=11)
     make_trajectories()
+    make_convergence()
+
+
+def make_convergence():
+    convergence_case("converge_small", O.OracleCfg(fc_units=64, n_samples=32, render_chunk_size=40960), seed=14,
+                     n_bank=10240, n_test=1024, batch=256, steps=int(os.environ.get("SNERF_CONV_STEPS", "400")), eval_every=50)
 
 
 def make_trajectories():
