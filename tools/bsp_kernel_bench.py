@@ -17,7 +17,7 @@ L = _lib.lib()
 if os.environ.get("SNERF_BENCH_KC_GRID"):      # persistent grid of the K-contiguous launches (default: two workgroups per CU)
     L.snerf_test_set_kc_grid(int(os.environ["SNERF_BENCH_KC_GRID"]))
 dev = "cuda:0"
-P, W = 262144, 512
+P, W = int(os.environ.get("SNERF_BENCH_P", "262144")), 512      # SNERF_BENCH_P: rows (points) of the launch
 g = torch.Generator().manual_seed(0)
 X = (torch.rand(P, W, generator=g) * 2 - 1).to(dev)
 Wm = (torch.randn(W, W, generator=g) * 0.06).to(dev)
@@ -47,7 +47,7 @@ for _ in range(reps if which in ("all", "kc", "dx") else 0):   # dX with the der
     _lib.check(L.snerf_test_bsp_kc(p(G), None, W, p(Wm), None, P, W, W, 0, 0, 0, 1.0, 3, p(H), p(sign), p(D), None, p(cs), None, None, None, 0, planes, st), "dx")
 Cw = torch.empty(W, W, device=dev)
 for _ in range(reps if which in ("all", "dw") else 0):   # dW, 64 splits
-    _lib.check(L.snerf_test_bsp_dw(p(G), W, p(X), W, P, W, W, 0, 0, 4096, 0, p(Cw), planes, st), "dw")
+    _lib.check(L.snerf_test_bsp_dw(p(G), W, p(X), W, P, W, W, 0, 0, P // 64, 0, p(Cw), planes, st), "dw")
 S32 = torch.empty(P, 32, device=dev)
 W32 = (torch.randn(32, W, generator=g) * 0.05).to(dev)
 for _ in range(reps if which in ("all", "narrow") else 0):   # 32-wide head
