@@ -3,7 +3,8 @@
 # rendered twice): FETCH_SIZE / WRITE_SIZE in passes of their own, summed over all kernels of the process; counter units from the
 # calibration of tools/pmc_traffic.sh (<pmc dir>/pmc_hbm_traffic.json).   usage: pmc_inference.sh <out dir under gpurun_out> <pmc dir> [mode]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/$1; CAL=gpurun_out/$2/pmc_hbm_traffic.json; MODE=${3:-f16x2}; mkdir -p $O
+# <pmc dir>: a directory under gpurun_out/ of the same call, or a committed one (profiles/rNN: the units are constants of the counter)
+O=gpurun_out/$1; if [ -f $2/pmc_hbm_traffic.json ]; then CAL=$2/pmc_hbm_traffic.json; else CAL=gpurun_out/$2/pmc_hbm_traffic.json; fi; MODE=${3:-f16x2}; mkdir -p $O
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -o t -- python3 tools/inference_rate.py 40960 lean $MODE > $O/$c.log 2>&1 || { tail -5 $O/$c.log; exit 1; }
 done
