@@ -41,6 +41,10 @@ FLOPS_PER_SAMPLE_TRAIN = 31_453_696  # main 3*F_m + sc (F_s + 2*
 FLOPS_PER_SAMPLE_TRAIN_SATNERF = 3 * 2 * 2_629_632 + 3 * 2 * 2_363_904 - 1024
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2500.0       # same guide: "Peak BF16/FP16 MFMA ~2.5 PF dense"
+# What a bare loop of the product's v_mfma_f32_32x32x16_f16 SUSTAINS on real operands under the 1,400 W package cap (the 2.5 PF are a
+# zero-operand figure: profiles/r05/power_cap.md, tools/ablate/mfma_power.hip; 1,677 / 1,707 / 1,712 TFLOP/s on two boxes).  Reported next
+# to `peak`, never instead of it.
+FP16_MFMA_SUSTAINED_TFLOPS = 1700.0
 HBM_ACHIEVABLE_BPS = 6.3e12          # same guide: achievable HBM3E streaming rate (peak 8 TB/s)
 ALGORITHMIC_BYTES_PER_RAY = 3700     # rays + targets in, per-ray results out, parameters amortised
 
@@ -587,6 +591,11 @@ def main():
                        f"{int(mult)} x v_mfma_f32_32x32x16_f16 per 32x32x16 block; one-pass sine epilogue on the accumulators, planes + block "
                        "exponents out through LDS strips)"),
             "vs_fp32_mfma_peak": alg / FP32_MFMA_PEAK_TFLOPS,
+            "power_capped": {"sustained_peak": FP16_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": alg / FP16_MFMA_SUSTAINED_TFLOPS,
+                             "frac_mfma_issued_of_sustained": alg * mult / FP16_MFMA_SUSTAINED_TFLOPS,
+                             "step_mfma_floor_ms": flops_step_gpu * mult / (FP16_MFMA_SUSTAINED_TFLOPS * 1e12) * 1e3,
+                             "source": "profiles/r05/power_cap.md: the step holds the 1,400 W package cap at sclk ~1.57 GHz (2.4 nominal); a register-resident "
+                                       "32x32x16 fp16 MFMA loop on real operands sustains 1.68-1.71 PFLOP/s there (2.48 on zeros); measured on MI355X, not from the guide"},
             "launches": int(n), "avg_launch_ms": ms / max(n, 1),
             "measured_over": f"{prof_steps} extra steps after the timed region, main and sc pass serialised (SNERF_OVERLAP_SC=0 behaviour), "
                              "HIP events on the launch stream around every GEMM launch",
