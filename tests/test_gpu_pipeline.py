@@ -283,7 +283,7 @@ def test_adam_trajectory_through_trainloop(monkeypatch):
     assert np.allclose(traj, z["adam_traj"], rtol=0, atol=3e-4), (traj, z["adam_traj"])
 
 
-def _fixed_batch_loop(name, monkeypatch):
+def _fixed_batch_loop(name, monkeypatch, **pipe_extra):
     """TrainLoop (FlatAdam, gradient sinks, batch prefetch: the defaults) over a ray bank whose every batch is the fixture's batch:
     the rows repeated so that the loop's own epoch counter stays at 0 for the whole trajectory, sampled without shuffling."""
     from snerf_amd.framework.datasets import GpuRayBank
@@ -291,7 +291,7 @@ def _fixed_batch_loop(name, monkeypatch):
     z, meta, cfg = load_fixture(name)
     b = fixture_batch(z)
     N, steps = b["rays"].shape[0], meta["steps"]
-    pipe, _ = _pipeline_for(cfg, N, meta["seed"], run_extra={"shuffle_dataset": False})
+    pipe, _ = _pipeline_for(cfg, N, meta["seed"], run_extra={"shuffle_dataset": False}, **pipe_extra)
     rep = steps + 3
     rows = {"rays": b["rays"], "rgbs": b["rgbs"], "extras": b["extras"], "semantic": b["semantic"].to(torch.uint8),
             "semantic_sparsity_mask": b["mask"]}
@@ -568,3 +568,24 @@ def test_training_converges_like_the_reference(mode, monkeypatch):
     for k, bar in zip(("psnr", "acc", "miou", "depth_mae"), _CONV_BARS[mode]):
         assert worst[k] <= bar, (k, worst[k], bar, curves[k], z["run0_" + k].tolist())
     assert curves["psnr"][-1] > curves["psnr"][0] + 15.0
+
+
+def test_one_plane_trajectory_within_the_reference_noise_at_full_width(monkeypatch):
+    """The REDUCED mode at W = 512 / S = 64 -- where the trunk forward of a training pass is ONE persistent launch (bsp_trunk.hip) --
+    against the reference's 10-step optimiser trajectory: its loss curve may leave the reference's by no more than the reference
+    itself does when its initial weights carry 1e-3 relative noise (`yard_total_noise_1e-3` of the fixture, made by tools/gen_golden.py
+    with the reference's own modules; the same from 1e-4 noise is printed beside it).  Measured on MI355X (round 5): max |dloss| 2.97e-3
+    over the 11 points, against the reference's envelopes 8.46e-3 (1e-3 noise) and 2.0e-3 (1e-4 noise): the bar is the 1e-3 envelope."""
+    z, meta, pipe, loop, steps = _fixed_batch_loop("traj10_full", monkeypatch, mfma_precision="f16x1")
+    assert pipe.models["coarse"].spec.mfma == "f16x1"
+    got = []
+    for it in range(steps):
+        got.append(float(loop.step(it)["loss"]))
+    got.append(float(pipe.training_step({"rgb": loop.bank.batch(steps, loop.global_batch, shuffle=False)}, steps)["loss"]))
+    ref = z["traj_total"]
+    dev = np.abs(np.array(got) - ref)
+    env3, env4 = np.abs(z["yard_total_noise_1e-3"] - ref).max(), np.abs(z["yard_total_noise_1e-4"] - ref).max()
+    print(f"\ntraj10_full [f16x1]: max |dloss| {dev.max():.2e} (per step {np.round(dev, 5).tolist()}); the reference's own envelope under "
+          f"1e-3 weight noise {env3:.2e}, under 1e-4 {env4:.2e}")
+    assert dev.max() <= env3, (dev.tolist(), env3)
+    assert got[-1] < 0.5 * got[0]

@@ -231,7 +231,7 @@ def inference_case(name, cfg: O.OracleCfg, n_rays, seed):
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
-def trajectory_case(name, cfg: O.OracleCfg, n_rays, seed, steps, final_params=("fc_net.8.weight",), car_prob=0.2):
+def trajectory_case(name, cfg: O.OracleCfg, n_rays, seed, steps, final_params=("fc_net.8.weight",), car_prob=0.2, noise_rel=None):
     """a16 + a18 composed over MANY steps: the reference's renderer, its loss modules under the gates of
     semantic/components/training_step.py:22-92 and stock torch.optim.Adam(lr 5e-4, wd 0) (base_ray_pipeline.py:246-254) on ONE
     fixed batch (epoch 0 of a config whose first_beta_epoch is 0, so a training loop that counts epochs itself sees the same gates).
@@ -239,6 +239,11 @@ def trajectory_case(name, cfg: O.OracleCfg, n_rays, seed, steps, final_params=("
     (steps + 1 values), and the final values of `final_params` (+ the embedding).  Parameters regenerate from (cfg, seed)."""
     torch.manual_seed(0)
     cfgs, models, renderer, params = build_reference(cfg, seed)
+    if noise_rel:      # a yardstick run: the same trajectory from weights carrying `noise_rel` relative noise (only its loss curve is stored)
+        rng = np.random.default_rng(seed + 99)
+        with torch.no_grad():
+            for p in models["coarse"].parameters():
+                p.mul_(torch.from_numpy(1.0 + noise_rel * rng.standard_normal(tuple(p.shape))).float())
     b = O.synthetic_batch(n_rays, cfg.n_samples, seed=seed + 100, n_classes=max(cfg.n_classes, 2), car_prob=car_prob)
     bt = O.batch_to_torch(b)
     fix = {f"in_{k}": v for k, v in b.items()}
@@ -257,6 +262,8 @@ def trajectory_case(name, cfg: O.OracleCfg, n_rays, seed, steps, final_params=("
             break
         l.backward()
         opt.step()
+    if noise_rel:
+        return np.array(traj, dtype=np.float64)
     fix["traj_total"] = np.array(traj, dtype=np.float64)
     for k, v in terms.items():
         fix[f"traj_{k}"] = np.array(v, dtype=np.float64)
@@ -268,9 +275,17 @@ def trajectory_case(name, cfg: O.OracleCfg, n_rays, seed, steps, final_params=("
                 cfg={k: (list(v) if isinstance(v, tuple) else v) for k, v in vars(cfg).items()},
                 torch=torch.__version__, reference="wagnva/semantic-nerf-for-satellite-data@2025-03-21")
     fix["meta_json"] = np.array(json.dumps(meta))
+    return fix, traj
+
+
+def save_trajectory(name, fix, traj, steps, noisy=None):
+    if noisy:     # {"1e-3": curve}: the reference's own loss curve from weights with that much relative noise (yardstick of the one-plane mode)
+        for k, v in noisy.items():
+            fix[f"yard_total_noise_{k}"] = v
     path = os.path.join(OUT, f"{name}.npz")
     np.savez_compressed(path, **fix)
-    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, loss {traj[0]:.6f} -> {traj[-1]:.6f} over {steps} steps")
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, loss {traj[0]:.6f} -> {traj[-1]:.6f} over {steps} steps" +
+          ("".join(f"; noise {k}: max |dloss| {np.abs(v - fix['traj_total']).max():.2e}" for k, v in (noisy or {}).items())))
 
 
 def convergence_case(name, cfg: O.OracleCfg, seed, n_bank, n_test, batch, steps, eval_every, scene_seed=3, perturb_rel=(0.0, 1e-6, 1e-3)):
@@ -391,8 +406,14 @@ def make_convergence():
 
 def make_trajectories():
     small = dict(fc_units=32, n_samples=16, render_chunk_size=200)
-    trajectory_case("traj25_small", O.OracleCfg(first_beta_epoch=0, use_car_reg_loss=True, car_reg_loss_start=0, **small), 48, seed=12, steps=25)
-    trajectory_case("traj10_full", O.OracleCfg(first_beta_epoch=0), 16, seed=13, steps=10)
+    c = O.OracleCfg(first_beta_epoch=0, use_car_reg_loss=True, car_reg_loss_start=0, **small)
+    save_trajectory("traj25_small", *trajectory_case("traj25_small", c, 48, seed=12, steps=25), 25)
+    # the full-width trajectory also from weights with 1e-3 / 1e-4 relative noise: the reference-made yardstick for the one-plane mode at
+    # W = 512 (where its trunk runs as one persistent launch)
+    c = O.OracleCfg(first_beta_epoch=0)
+    fix, traj = trajectory_case("traj10_full", c, 16, seed=13, steps=10)
+    noisy = {k: trajectory_case("traj10_full", c, 16, seed=13, steps=10, noise_rel=float(k)) for k in ("1e-3", "1e-4")}
+    save_trajectory("traj10_full", fix, traj, 10, noisy)
 
 
 if __name__ == "__main__":
