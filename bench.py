@@ -152,6 +152,51 @@ def eager_gpu_baseline(rays, samples, device, steps=3):
             "sample": f"{steps} full train steps of {rays} rays x {samples} samples, render_chunk_size 40960 points"}
 
 
+def power_probe(loop, step0, seconds=1.5):
+    """Clock and package power WHILE the step runs, on this box: rocm-smi sampled from a thread beside ~`seconds` of extra steps AFTER the
+    timed region (read-only; nothing here touches the headline).  The step is bound by the package power cap (profiles/r05/power_cap.md):
+    the line carries the clock the firmware held and the watts it drew, so a reader can tell a slow box from a slow build."""
+    import re
+    import subprocess
+    import threading
+    samples, stop = [], threading.Event()
+
+    def smi():
+        while not stop.is_set():
+            try:
+                o = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+                c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", o)
+                w = re.search(r"Power \(W\): ([\d.]+)", o)
+                if c and w:
+                    samples.append((time.perf_counter(), int(c.group(1)), float(w.group(1))))
+            except Exception:
+                return
+            time.sleep(0.1)
+
+    try:
+        th = threading.Thread(target=smi, daemon=True)
+        th.start()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(4):
+                loop.step(step0 + n); n += 1
+            torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        stop.set()
+        th.join(timeout=6)
+        mid = sorted((c, w) for t, c, w in samples if t0 + 0.4 * (t1 - t0) <= t <= t1)
+        if not mid:
+            return None, n
+        return {"sclk_mhz": mid[len(mid) // 2][0], "package_power_w": sorted(w for _, w in mid)[len(mid) // 2], "samples": len(mid),
+                "nominal_sclk_mhz": 2400, "power_cap_w": 1400,
+                "how": "rocm-smi --showclocks --showpower from a thread beside %d extra steps after the timed region (median of the samples in the last 60 %%)" % n}, n
+    except Exception:
+        stop.set()
+        return None, 0
+
+
 def inference_rates(pipe, cfgs, device, samples, n_rays=40960 * 4):
     """Forward-only rays/s (SURVEY 8(d) asks for it next to the training number): one "image" of n_rays rays through
     (a) lean_inference -- rgb + depth + label only, no solar-correction pass, written in place per chunk -- and
@@ -470,6 +515,10 @@ def main():
             _lib.check(L.snerf_profile_end(C.byref(prof)), "snerf_profile_end")
         finally:
             _rend.OVERLAP_SC_PASS = saved
+    observed = None
+    if world == 1 and not args.no_profile:
+        observed, n_extra = power_probe(loop, step)
+        step += n_extra
     gloo = world > 1 and torch.distributed.get_backend() == "gloo"   # rehearsal rigs; RCCL reduces on the device
     tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else device)
     if world > 1:
@@ -594,6 +643,7 @@ def main():
             "power_capped": {"sustained_peak": FP16_MFMA_SUSTAINED_TFLOPS, "frac_of_sustained": alg / FP16_MFMA_SUSTAINED_TFLOPS,
                              "frac_mfma_issued_of_sustained": alg * mult / FP16_MFMA_SUSTAINED_TFLOPS,
                              "step_mfma_floor_ms": flops_step_gpu * mult / (FP16_MFMA_SUSTAINED_TFLOPS * 1e12) * 1e3,
+                             "observed_in_this_run": observed,
                              "source": "profiles/r05/power_cap.md: the step holds the 1,400 W package cap at sclk ~1.57 GHz (2.4 nominal); a register-resident "
                                        "32x32x16 fp16 MFMA loop on real operands sustains 1.68-1.71 PFLOP/s there (2.48 on zeros); measured on MI355X, not from the guide"},
             "launches": int(n), "avg_launch_ms": ms / max(n, 1),
