@@ -301,16 +301,20 @@ REDUCED_STATS = []   # measured errors of the one-plane mode (printed by tests/c
 def test_reduced_precision_mode_full_width(monkeypatch):
     """SNERF_FLAG_F16X1 -- one fp16 plane of the block-scaled tensors, one product: the mode of the reference's `precision = 16`
     runs (BASELINE.json configs[2] / [4]) -- at the headline width on the reference's own W = 512 fixture, through the SAME kernels
-    as the default (templated on the plane count).  REDUCED precision: the bars below are this build's own, UNPINNED (the
-    reference publishes no half-precision numbers and runs no such path here): outputs 5e-3 absolute (measured 7.4e-4), loss terms 1 %,
-    gradients within 10 % relative L2 of the default arithmetic's (measured 3.8 %) and finite.  The default is held to 1e-4 / 2e-4 right above."""
+    as the default (templated on the plane count).  REDUCED precision.  The reference publishes no half-precision numbers and runs no
+    such path here, so the yardsticks are made by the reference itself (tools/gen_golden.py: `yard_*_noise_*` of the fixture): the same
+    case from weights carrying 1e-3 relative noise moves its outputs by 5.6e-3 abs, its gradients by 3.5 % relative L2 (3e-4 noise:
+    1.7e-3, 1.0 %).  Bars: outputs within the 1e-3 yardstick (measured 7.4e-4: below even the 3e-4 one), loss terms 1 %, gradients
+    within 3x the 1e-3 yardstick of the default arithmetic's (measured 3.8 %) and finite.  The default is held to 1e-4 / 2e-4 right above."""
     from snerf_amd import ops, _lib
     dev = _dev()
     z, meta, cfg = load_fixture("sem_siren_full")
     pn = fixture_params(z, meta, cfg)
     b = fixture_batch(z)
     grads, outs = {}, {}
-    for name, flags, out_tol, loss_tol in (("f16x2", 0, OUT_TOL, 2e-4), ("f16x1", _lib.FLAG_F16X1, 5e-3, 1e-2)):
+    yard_out, yard_grad = float(z["yard_out_abs_noise_1e-3"]), float(z["yard_grad_rel_noise_1e-3"])
+    assert 1e-3 < yard_out < 2e-2 and 1e-2 < yard_grad < 1e-1
+    for name, flags, out_tol, loss_tol in (("f16x2", 0, OUT_TOL, 2e-4), ("f16x1", _lib.FLAG_F16X1, yard_out, 1e-2)):
         monkeypatch.setattr(ops, "BASE_FLAGS", flags)
         gp = _gpu_params(pn, dev, requires_grad=True)
         emb_g = torch.from_numpy(O.init_embedding_numpy(cfg, meta["seed"])).to(dev).requires_grad_(True)
@@ -332,9 +336,11 @@ def test_reduced_precision_mode_full_width(monkeypatch):
         outs[name] = worst
     assert all(torch.isfinite(g).all() for g in grads["f16x1"].values())
     rel = {k: float(rel_err(grads["f16x1"][k], grads["f16x2"][k])) for k in grads["f16x2"] if float(grads["f16x2"][k].abs().max()) > 0}
-    REDUCED_STATS.append({"worst_output_abs_err": outs["f16x1"], "worst_grad_rel_l2": max(rel.values()), "default_worst_output_abs_err": outs["f16x2"]})
+    REDUCED_STATS.append({"worst_output_abs_err": outs["f16x1"], "worst_grad_rel_l2": max(rel.values()), "default_worst_output_abs_err": outs["f16x2"],
+                          "reference_under_1e-3_weight_noise": {"outputs_abs": yard_out, "grad_rel_l2": yard_grad},
+                          "reference_under_3e-4_weight_noise": {"outputs_abs": float(z["yard_out_abs_noise_3e-4"]), "grad_rel_l2": float(z["yard_grad_rel_noise_3e-4"])}})
     print("f16x1 at W=512:", REDUCED_STATS[-1])
-    assert max(rel.values()) <= 1e-1, sorted(rel.items(), key=lambda kv: -kv[1])[:3]
+    assert max(rel.values()) <= 3.0 * yard_grad, sorted(rel.items(), key=lambda kv: -kv[1])[:3]
 
 
 def test_forward_backward_capture_in_a_hip_graph():

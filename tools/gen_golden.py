@@ -128,7 +128,7 @@ def losses_for_epoch(cfg, res, batch, epoch, depth_res=None):
 
 
 def make_case(name, cfg: O.OracleCfg, n_rays, seed, epoch, with_depth=False, store_params=True,
-              per_sample=True, grad_mode="full", adam_steps=0, mask_frac=None, car_prob=0.2, full_grads=()):
+              per_sample=True, grad_mode="full", adam_steps=0, mask_frac=None, car_prob=0.2, full_grads=(), yard_noise=()):
     torch.manual_seed(0)
     cfgs, models, renderer, params = build_reference(cfg, seed)
     b = O.synthetic_batch(n_rays, cfg.n_samples, seed=seed + 100, n_classes=max(cfg.n_classes, 2), car_prob=car_prob)
@@ -177,6 +177,30 @@ def make_case(name, cfg: O.OracleCfg, n_rays, seed, epoch, with_depth=False, sto
     if store_params:
         for k, v in params.items():
             fix[f"param_{k}"] = v
+
+    for eps in yard_noise:
+        # Yardsticks for the REDUCED-precision mode, made by the reference: the same case from weights carrying `eps` relative Gaussian
+        # noise -- the worst absolute deviation of any stored output, the worst relative deviation of a loss term and the worst relative
+        # L2 deviation of a parameter gradient from the clean run above.
+        torch.manual_seed(0)
+        _, models_n, renderer_n, _ = build_reference(cfg, seed)
+        rng = np.random.default_rng(seed + 99)
+        with torch.no_grad():
+            for p_ in models_n["coarse"].parameters():
+                p_.mul_(torch.from_numpy(1.0 + float(eps) * rng.standard_normal(tuple(p_.shape))).float())
+        res_n = render_with_u(renderer_n, models_n, bt["rays"], bt["extras"], bt["u"])
+        ld_n = losses_for_epoch(cfg, res_n, bt, epoch, None)
+        sum(ld_n.values()).backward()
+        worst_out = max(float((res_n[k[4:]].detach() - torch.from_numpy(fix[k])).abs().max()) for k in fix
+                        if k.startswith("out_") and k != "out_semantic_label_coarse" and k[4:] in res_n)
+        worst_loss = max(abs(ld_n[k].item() - ld[k].item()) / max(1.0, abs(ld[k].item())) for k in ld_n)
+        gn = {k: p_.grad.detach().numpy() for k, p_ in models_n["coarse"].named_parameters()}
+        worst_grad = max(float(np.linalg.norm((gn[k] - grads[k]).ravel()) / (np.linalg.norm(grads[k].ravel()) + 1e-30)) for k in gn
+                         if float(np.abs(grads[k]).max()) > 0)
+        fix[f"yard_out_abs_noise_{eps}"] = np.float64(worst_out)
+        fix[f"yard_loss_rel_noise_{eps}"] = np.float64(worst_loss)
+        fix[f"yard_grad_rel_noise_{eps}"] = np.float64(worst_grad)
+        print(f"{name}: reference under {eps} weight noise: outputs {worst_out:.2e} abs, loss terms {worst_loss:.2e} rel, gradients {worst_grad:.2e} rel L2")
 
     if adam_steps:
         # a18: Adam(lr=5e-4, wd=0) trajectory on the reference model (base_ray_pipeline.py:246-254)
@@ -364,6 +388,10 @@ def main():
         # I: long optimiser trajectories of the whole composed step -- 25 steps at W = 32 with L_t on, 10 steps at the full width
         make_trajectories()
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "--full-width":     # G only (+ the yardsticks of the REDUCED-precision mode, round 5)
+        make_case("sem_siren_full", O.OracleCfg(), 16, seed=8, epoch=2, store_params=False, per_sample=False,
+                  grad_mode="sample", full_grads=FULL_GRADS_SEM, yard_noise=("1e-3", "3e-4"))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--convergence":    # J: the reference trained on the learnable synthetic scene
         make_convergence()
         return
@@ -389,7 +417,7 @@ def main():
               40, seed=7, epoch=0)
     # G: full width (W=512, S=64), few rays; weights regenerate from the seed
     make_case("sem_siren_full", O.OracleCfg(), 16, seed=8, epoch=2, store_params=False, per_sample=False,
-              grad_mode="sample", full_grads=FULL_GRADS_SEM)
+              grad_mode="sample", full_grads=FULL_GRADS_SEM, yard_noise=("1e-3", "3e-4"))
     make_case("satnerf_full_c1", O.OracleCfg(model="satnerf", n_samples=32), 16, seed=9, epoch=2,
               store_params=False, per_sample=False, grad_mode="sample")
     # H: seam-3 inference on explicit xyz/z_vals
