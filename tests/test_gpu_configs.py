@@ -19,7 +19,10 @@ oracle's gradients of the subset alone.
 Tolerances: 1e-4 absolute on every rendered tensor, class argmax exact wherever the oracle's top-2 margin exceeds
 twice the measured logit error, z_vals bit-exact, parameter gradients 2e-4 relative L2 (GRAD_REL_TOL: ten times the largest
 error measured on any tensor of any case; BASELINE.json north_star: 1e-4 outputs, argmax bit-exact).  The bf16 mode (REDUCED precision, the reference's `precision = 16`: here the one-plane mode) is judged
-PSNR-style: outputs within 5e-3, class agreement >= 98 %, loss terms within 1 %, gradients within 3 % -- stated in the test.
+PSNR-style: outputs within 5e-3, class agreement >= 98 %, loss terms within 1 %, gradients within 3 % -- stated in the test.  These bars
+are what the REFERENCE itself does when its weights carry 1e-3 relative noise (tests/golden/sem_siren_full.npz, yard_*: outputs
+5.6e-3, gradients 3.5 %; tools/gen_golden.py), and the mode's training outcome is pinned to the reference's own runs in
+tests/test_gpu_pipeline.py (400-step convergence on the synthetic scene, the full-width trajectory inside the reference's noise envelope).
 """
 import pytest
 import torch
